@@ -1,0 +1,326 @@
+/*
+ * gpis.h — C ABI of the MI355X-native sparse-convolution GPIS hot path.
+ *
+ * This is the drop-in boundary: the entry points below are what a binding in the
+ * reference (a `Medium` subclass registered in MediumFactory.cpp:13-22) would call in
+ * place of the CPU code in
+ *   src/core/media/SparseConvolutionNoiseMedium.cpp   (SCNM.cpp)
+ *   src/core/media/GaussianProcessMedium.cpp          (GPM.cpp)
+ *   src/core/math/SparseConvolutionNoise.cpp          (SCN.cpp)
+ *   src/core/math/GPFunctions.cpp                     (GPF.cpp)
+ * Plain pointers and sizes only; no C++ types, no torch types, no exceptions.
+ *
+ * Memory convention: every `*_batch` entry takes DEVICE pointers (hipMalloc'd, or a
+ * torch tensor's data_ptr) and enqueues on `stream` (a hipStream_t passed as void*,
+ * NULL = the null stream) without synchronising.  The `*_host` variants take HOST
+ * pointers, stage through an internal device workspace and synchronise before
+ * returning — they are what a batch-of-one `Medium` adapter uses.
+ *
+ * All functions return GPIS_OK (0) or a negative gpis_status; gpis_last_error()
+ * returns a thread-local message for the last failure.
+ */
+#ifndef GPIS_H_
+#define GPIS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPIS_ABI_VERSION 1
+
+typedef enum gpis_status {
+    GPIS_OK = 0,
+    GPIS_ERR_INVALID_ARG = -1,   /* bad pointer / size / enum */
+    GPIS_ERR_UNSUPPORTED = -2,   /* a parameter combination outside the built scope */
+    GPIS_ERR_DEVICE = -3,        /* HIP runtime error (message in gpis_last_error) */
+    GPIS_ERR_NO_DEVICE = -4      /* no gfx950 device / extension cannot run */
+} gpis_status;
+
+/* GPCorrelationContext, src/core/math/GaussianProcess.hpp:26-31 (same numeric order). */
+typedef enum gpis_corr_ctx {
+    GPIS_CTX_GLOBAL = 0,
+    GPIS_CTX_RENEWAL_PLUS = 1,
+    GPIS_CTX_RENEWAL = 2,
+    GPIS_CTX_NONE = 3
+} gpis_corr_ctx;
+
+/* SparseConv1DSamplingScheme, src/core/media/Medium.hpp:40-44. */
+typedef enum gpis_scheme_1d { GPIS_UNI = 0, GPIS_NEE = 1, GPIS_MIS = 2 } gpis_scheme_1d;
+
+/* Mean functions, src/core/math/GPFunctions.hpp:867-1005. */
+typedef enum gpis_mean_type {
+    GPIS_MEAN_HOMOGENEOUS = 0,   /* offset                       GPF.hpp:867-901  */
+    GPIS_MEAN_SPHERICAL = 1,     /* |p-c| - r                    GPF.hpp:903-945  */
+    GPIS_MEAN_LINEAR = 2         /* max((p-ref).dir*scale, min)  GPF.hpp:947-1005 */
+} gpis_mean_type;
+
+/* ProceduralNoiseVec ramps used for the non-stationary length scale, GPF.cpp:87-95. */
+typedef enum gpis_ramp_type {
+    GPIS_RAMP_BOTTOM_TOP = 0,    /* along y */
+    GPIS_RAMP_LEFT_RIGHT = 1,    /* along x */
+    GPIS_RAMP_FRONT_BACK = 2     /* along z */
+} gpis_ramp_type;
+
+typedef struct gpis_mean {
+    int32_t type;          /* gpis_mean_type */
+    float radius;          /* spherical */
+    float offset;          /* homogeneous */
+    float scale;           /* linear */
+    float min;             /* linear (default -FLT_MAX) */
+    int32_t _pad;
+    double center[3];      /* spherical centre / linear reference_point */
+    double dir[3];         /* linear direction (normalised by gpis_create as LinearMean::fromJson does) */
+} gpis_mean;
+
+/*
+ * All JSON keys of the hot path (SURVEY.md §5 "Config / flags"):
+ *   medium:      SCNM.cpp:57-73, GPM.cpp:97-126, Medium.cpp:37
+ *   covariance:  GPF.cpp:654-679 (squared_exponential), GPF.hpp:1481-1484 (localScale),
+ *                GPF.hpp:1134-1137 (lateralScale)
+ *   wrapper:     GPF.hpp:2211-2217 + GPF.cpp:1590-1606 (proc_nonstationary: ls ramp, multiResolutionGrid)
+ */
+typedef struct gpis_params {
+    uint32_t abi_version;            /* must be GPIS_ABI_VERSION */
+    /* --- sparse_conv_noise medium --- */
+    float step_size;                 /* "step_size"  default 0.01 */
+    uint32_t min_step;               /* "min_step"   default 8 */
+    uint32_t seed;                   /* "seed"       _globalSeed */
+    float impulse_density;           /* "impulse_density" */
+    int32_t single_realization;      /* "single_realization" */
+    int32_t isotropic_3d_sampling;   /* "isotropic_3D_sampling" (iso-RAY space: SCN.cpp:17 hard-wires it) */
+    int32_t sampling_1d;             /* "1D_sampling" */
+    int32_t scheme_1d;               /* "1D_sampling_scheme" gpis_scheme_1d */
+    int32_t correlation_xy;          /* "1D_gradient_correlationXY" */
+    int32_t surf_vol_phase_separate; /* "surf_vol_phase_separate" */
+    float surf_vol_phase_amp_thresh; /* "surf_vol_phase_amp_thresh" */
+    /* --- gaussian_process medium base --- */
+    int32_t correlation_context;     /* "correlation_context" gpis_corr_ctx (required) */
+    int32_t max_bounces;             /* "max_bounces" default 1024 */
+    float sigma_a[3];                /* "sigma_a" */
+    float sigma_s[3];                /* "sigma_s" */
+    float density;                   /* "density" */
+    /* --- squared_exponential covariance --- */
+    float sigma;                     /* "sigma" */
+    float length_scale;              /* "lengthScale" */
+    float aniso[3];                  /* "aniso" */
+    int32_t use_aniso_mtx;           /* "useAnisoMtx" */
+    float aniso_mtx[9];              /* "anisoMtx" row-major, used when use_aniso_mtx */
+    float local_scale;               /* "localScale" (_kernelScale, default 3) */
+    /* --- proc_nonstationary wrapper (0 = plain stationary kernel) --- */
+    int32_t nonstationary;           /* 1: ProceduralNonstationaryCovariance with an "ls" ramp */
+    int32_t multi_resolution_grid;   /* "multiResolutionGrid" */
+    int32_t ls_ramp_type;            /* gpis_ramp_type */
+    int32_t _pad0;
+    double ls_min, ls_max;           /* ramp "min","max" */
+    double ls_start, ls_end;         /* ramp "start","end" */
+    /* --- mean(s) --- */
+    gpis_mean mean;                  /* GaussianProcess::_mean,  _id = 0 */
+    int32_t has_mean_additional;     /* GaussianProcess::_mean_additional (CSG min), _id_additional = 1 */
+    int32_t _pad1;
+    gpis_mean mean_additional;
+} gpis_params;
+
+/*
+ * One ray segment handed to Medium::sampleDistance / Medium::transmittance
+ * (Medium.hpp:104-108): the Ray (math/Ray.hpp), the caller-owned Medium::MediumState
+ * (Medium.hpp:59-88) and RayInfo (MediumSample.hpp:14-18), plus the single
+ * PathSampleGenerator::next1D() the path consumes (SCNM.cpp:129).  128 bytes.
+ */
+typedef struct gpis_ray_in {
+    float pos[3];
+    float dir[3];
+    float near_t;
+    float far_t;              /* may be +inf: clamped to near_t+2000 (GPM.cpp:229-231) */
+    uint32_t pixel[2];        /* info.pixelSampleSegment.xy */
+    uint32_t spp;             /* info.pixelSampleSegment.z  */
+    uint32_t segment;         /* info.pixelSampleSegment.w  (bounce index, PathTracer.cpp:64) */
+    uint32_t scene_seed;      /* info.sceneSeed */
+    float info_t;             /* info.t */
+    float u_jitter;           /* sampler.next1D() */
+    uint32_t first_scatter;   /* state.firstScatter */
+    int32_t bounce;           /* state.bounce */
+    float last_val;           /* state.lastVal */
+    int32_t last_gp_id;       /* state.lastGPId */
+    int32_t _pad;
+    double last_aniso[3];     /* state.lastAniso */
+    double _reserved[3];
+} gpis_ray_in;
+
+/*
+ * Result of one sampleDistance call: the MediumSample fields the path writes
+ * (GPM.cpp:224-340) and the MediumState updates the caller must apply:
+ *   state.lastAniso = aniso; state.lastVal = last_val; state.lastGPId = gp_id;
+ *   state.firstScatter = false (when gradient_sampled); state.bounce++; state.info.t += sample_t.
+ * 96 bytes.
+ */
+typedef struct gpis_seg_out {
+    double t;                 /* intersect t (double, SCNM.cpp:102) */
+    double aniso[3];          /* sample.aniso = sampled gradient */
+    float sample_t;           /* sample.t = min(float(t), maxT) */
+    float continued_t;        /* sample.continuedT */
+    float weight[3];          /* sample.weight */
+    float continued_weight[3];
+    float p[3];               /* sample.p */
+    float last_val;           /* state.lastVal after the call */
+    int32_t exited;           /* sample.exited */
+    int32_t ok;               /* return value of sampleDistance (0 → caller terminates the path) */
+    int32_t gp_id;            /* sample.gpId */
+    int32_t scheme;           /* sample.sparseConv1DSamplingScheme */
+} gpis_seg_out;
+
+/*
+ * The realization handle MediumSample.ctxt points to (GPContextSparseConvNoise,
+ * SparseConvolutionNoiseMedium.hpp:11-16) reduced to its mutable part: the
+ * pathwise-update conditioning coefficients (SCN.hpp:7-21).  32 bytes.
+ */
+typedef struct gpis_cond_coeff {
+    float value_scale;
+    float gradient_scale[3];
+    float ray_origin[3];
+    uint32_t n_evals;         /* noise evaluations spent on this segment (diagnostic) */
+} gpis_cond_coeff;
+
+/*
+ * A single noise query: SparseConvolutionNoiseRealization::evaluateValue /
+ * evaluateGradient (SCN.cpp:73-99) — unit-test surface.  `t_segment` is the
+ * `t` argument (distance along the current segment); `info_t` is RayInfo::t.  96 bytes.
+ */
+typedef struct gpis_query {
+    float p[3];
+    float dir[3];
+    float t_segment;
+    float info_t;
+    uint32_t pixel[2];
+    uint32_t spp;
+    uint32_t segment;
+    uint32_t scene_seed;
+    uint32_t _pad[3];
+    gpis_cond_coeff coeff;    /* conditioning state to evaluate under (all-zero = unconditioned) */
+} gpis_query;
+
+/* Input of neePDF / neeGrad (SCN.cpp:652-743). 96 bytes. */
+typedef struct gpis_nee_query {
+    float ray_dir[3];
+    float normal[3];
+    float p[3];
+    float t_segment;          /* neePDF's `tSegment` */
+    float info_t;
+    uint32_t pixel[2];
+    uint32_t spp;
+    uint32_t segment;
+    uint32_t scene_seed;
+    gpis_cond_coeff coeff;
+} gpis_nee_query;
+
+typedef struct gpis_medium gpis_medium;   /* opaque handle */
+
+/* Derived constants the path precomputes once (GPF.cpp:654-679, 696-709, 741-760);
+ * exposed so tests can pin them against the oracle. */
+typedef struct gpis_derived {
+    float world_to_local[9];   /* row-major */
+    float local_to_world[9];
+    float kernel_radius_world; /* splattingKernelRadius(false, 1) */
+    float kernel_radius_iso;   /* splattingKernelRadius(true, 1)  */
+    float norm3d_world;        /* sqrt(sparseConvNoiseVariance3D(world)) at scale 1 */
+    float norm3d_iso;          /* sqrt(sparseConvNoiseVariance3D(iso)) */
+    float norm1d;              /* sqrt(sparseConvNoiseVariance1D) */
+    uint32_t impulses_per_cell;
+    int32_t activate_conditioning; /* SCN.cpp:21 */
+    int32_t effective_scheme_1d;   /* SCN.cpp:23-26 */
+    int32_t multi_resolution;      /* SCN.cpp:30 */
+    int32_t fast_path;             /* 1 when the single-realization cell-table kernels are in use */
+} gpis_derived;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+
+/* Replaces SparseConvolutionNoiseMedium::fromJson + prepareForRender
+ * (SCNM.cpp:57-73, GPM.cpp:97-126,152-158).  `device` = HIP device ordinal. */
+int gpis_create(const gpis_params *params, int device, gpis_medium **out);
+int gpis_destroy(gpis_medium *m);
+int gpis_get_derived(const gpis_medium *m, gpis_derived *out);
+const char *gpis_last_error(void);
+/* Fills `p` with the reference's defaults (SCNM.cpp:17-34, GPM.cpp:86-95, GPF.hpp:1729,1784). */
+void gpis_default_params(gpis_params *p);
+
+/* ---- the hot path (device pointers) --------------------------------------------- */
+
+/* Medium::sampleDistance for n independent segments (GPM.cpp:221-341 → SCNM.cpp:102-183,
+ * 93-100).  `coeff` may be NULL. */
+int gpis_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays,
+                               gpis_seg_out *out, gpis_cond_coeff *coeff, void *stream);
+
+/* Medium::transmittance (GPM.cpp:343-393): visible[i] = 1 if the segment exits, else 0
+ * (the reference returns Vec3f(1) / Vec3f(0)). */
+int gpis_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays,
+                             uint8_t *visible, void *stream);
+
+/* SparseConvolutionNoiseRealization::evaluateValue / evaluateGradient (SCN.cpp:73-99). */
+int gpis_eval_value_batch(gpis_medium *m, size_t n, const gpis_query *q,
+                          float *value, int32_t *gp_id, void *stream);
+int gpis_eval_gradient_batch(gpis_medium *m, size_t n, const gpis_query *q,
+                             float *grad3, void *stream);
+
+/* SparseConvolutionNoiseRealization::conditioning (SCN.cpp:431-595): q[i].p/dir/... is the
+ * segment start; target_val / target_grad3 are state.lastVal / state.lastAniso. */
+int gpis_conditioning_batch(gpis_medium *m, size_t n, const gpis_query *q,
+                            const float *target_val, const float *target_grad3,
+                            gpis_cond_coeff *coeff_out, void *stream);
+
+/* SparseConvolutionNoiseRealization::neePDF / neeGrad (SCN.cpp:652-743). */
+int gpis_nee_pdf_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *pdf, void *stream);
+int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *grad3, void *stream);
+
+/* Bit-exact primitives (MathUtil.hpp:179-224, UniformSampler.hpp:41-75, BitManip.hpp:47-50):
+ * out[i] = xxhash32 of `arity` (1..4) words at words[i*arity..]; and the PCG32 stream
+ * after set_state(state[i]) — `count` raw nextI() draws each. */
+int gpis_xxhash32_batch(gpis_medium *m, size_t n, int arity, const uint32_t *words,
+                        uint32_t *out, void *stream);
+int gpis_pcg32_stream_batch(gpis_medium *m, size_t n, const uint64_t *state, uint32_t count,
+                            uint32_t *out, void *stream);
+
+/* ---- host-pointer conveniences (synchronous) ------------------------------------ */
+int gpis_sample_distance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays,
+                              gpis_seg_out *out, gpis_cond_coeff *coeff);
+int gpis_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible);
+int gpis_eval_value_host(gpis_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id);
+int gpis_eval_gradient_host(gpis_medium *m, size_t n, const gpis_query *q, float *grad3);
+
+/* ---- measurement ---------------------------------------------------------------- */
+
+/* Device counters: noise evaluations (evaluateValue/evaluateGradient-equivalents,
+ * conditioning evaluations included) and segments, accumulated since the last reset.
+ * Synchronises the device. */
+int gpis_get_counters(gpis_medium *m, uint64_t *n_eval, uint64_t *n_seg);
+int gpis_reset_counters(gpis_medium *m);
+
+/* ---- tile → ray-batch driver (SURVEY.md §8d "Scene S", §8f-1) -------------------- */
+
+typedef struct gpis_scene_s {
+    uint32_t width, height;
+    uint32_t spp_begin, spp_count;    /* sample indices [spp_begin, spp_begin+spp_count) */
+    uint32_t scene_seed;              /* 0xBA5EBA11 */
+    uint32_t tile_size;               /* 16 (PathTraceIntegrator.hpp:27) */
+    float cam_pos[3];                 /* (0,0,4) */
+    float cam_fov_deg;                /* 35 */
+    float bound_radius;               /* 1.5 */
+    float light_dir[3];               /* (0.5,0.7,0.5)/|.| (normalised by the driver) */
+    float light_radiance;             /* 1 */
+    uint32_t y_begin, y_count;        /* image rows rendered by this call (tile-row sharding) */
+} gpis_scene_s;
+
+void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp);
+
+/* Renders rows [y_begin, y_begin+y_count) × all columns × spp_count samples of scene S and
+ * ACCUMULATES sum-of-radiance into radiance_sum[height*width] (float, device pointer,
+ * indexed y*width+x; caller divides by total spp).  Runs primary sampleDistance, shading,
+ * one shadow transmittance per hit.  hit_count (device, may be NULL) accumulates per-pixel hits. */
+int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum,
+                        uint32_t *hit_count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPIS_H_ */

@@ -1,0 +1,87 @@
+/*
+ * gpis_oracle.h — TEST INFRASTRUCTURE (not product code).
+ *
+ * CPU restatement, in plain C, of the reference's sparse-convolution GPIS path.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (sparse-conv-gpis-tungsten_amd/) never links, includes or calls it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - integer layer (xxhash32 x4, PCG32, normalizedUint, Bernoulli, next3D draw order),
+ *     Duff ONB, Vec3f helpers, Box–Muller, and every Eigen expression form the path uses:
+ *     pinned bit-exactly against the REAL reference compiled in place (oracle/_ref, see
+ *     oracle/ref_probe.cpp) by tests/test_oracle_vs_ref.py;
+ *   - the float chain end-to-end (evaluateValue / evaluateGradient, world space, SE kernel):
+ *     pinned by the three known-answer values the reference itself produced in this image,
+ *     recorded in SURVEY.md §8c;
+ *   - everything else (iso-ray space, 1D, conditioning, multi-resolution, NEE, medium
+ *     march): a line-by-line restatement with NO reference-produced vector available
+ *     (the evaluator cannot be built here without Boost/FFTW stand-ins) → "parity unpinned".
+ *
+ * The entry points mirror include/gpis.h one-for-one but take HOST pointers.
+ */
+#ifndef GPIS_ORACLE_H_
+#define GPIS_ORACLE_H_
+
+#include "gpis.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_medium oracle_medium;
+
+int oracle_create(const gpis_params *params, oracle_medium **out);
+void oracle_destroy(oracle_medium *m);
+int oracle_get_derived(const oracle_medium *m, gpis_derived *out);
+void oracle_default_params(gpis_params *p);
+/* worker threads used by the *_batch functions and the renderer (default 1) */
+void oracle_set_threads(oracle_medium *m, int n);
+
+int oracle_sample_distance_batch(oracle_medium *m, size_t n, const gpis_ray_in *rays,
+                                 gpis_seg_out *out, gpis_cond_coeff *coeff);
+int oracle_transmittance_batch(oracle_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible);
+int oracle_eval_value_batch(oracle_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id);
+int oracle_eval_gradient_batch(oracle_medium *m, size_t n, const gpis_query *q, float *grad3);
+int oracle_conditioning_batch(oracle_medium *m, size_t n, const gpis_query *q, const float *target_val,
+                              const float *target_grad3, gpis_cond_coeff *coeff_out);
+int oracle_nee_pdf_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, float *pdf);
+int oracle_nee_grad_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, float *grad3);
+
+int oracle_xxhash32_batch(size_t n, int arity, const uint32_t *words, uint32_t *out);
+int oracle_pcg32_stream_batch(size_t n, const uint64_t *state, uint32_t count, uint32_t *out);
+
+void oracle_get_counters(oracle_medium *m, uint64_t *n_eval, uint64_t *n_seg);
+void oracle_reset_counters(oracle_medium *m);
+
+void oracle_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp);
+int oracle_render_scene_s(oracle_medium *m, const gpis_scene_s *s, float *radiance_sum, uint32_t *hit_count);
+/* Scene-S building blocks (so the GPU driver's ray generation can be checked on its own):
+ * primary ray + draws of sample (x, y, spp); returns 0 if the ray misses the bounding sphere. */
+int oracle_scene_s_primary(const gpis_scene_s *s, uint32_t x, uint32_t y, uint32_t spp,
+                           gpis_ray_in *ray, float *u_shadow);
+
+/* ---- small pieces exposed for pinning against oracle/_ref ------------------------- */
+void oracle_cell3d_draws(uint64_t state, uint32_t k, float *out);   /* k*{x,y,z,u_w} */
+float oracle_normalized_uint(uint32_t i);
+void oracle_tangent_frame(const float *n, float *out9);             /* tangent, bitangent, normal */
+void oracle_frame_to_local(const float *n, const float *p, float *out3);
+void oracle_frame_to_global(const float *n, const float *p, float *out3);
+void oracle_vec3_normalized(const float *v, float *out3);
+void oracle_sample_standard_normal2(uint64_t state, uint32_t draws, double *out);
+void oracle_sample_xy_over_sqrt2(uint64_t state, double *out2);
+float oracle_eig_dist2_ab(const float *ab, const float *m9);
+float oracle_eig_dot_col(const float *ab, const float *m9, int c);
+void oracle_eig_matvec_div(const float *m9, const float *v, float s, float *out3);
+void oracle_eig_matvec_mul(const float *m9, const float *v, float s, float *out3);
+void oracle_eig_matvec(const float *m9, const float *v, float *out3);
+void oracle_eig_inverse3(const float *m9, float *out9);
+void oracle_eig_second_deriv_inv(const float *m9, float *out9);
+void oracle_eig_scaled_matmul(float amplitude, const float *a9, const float *b9, float *out9);
+void oracle_eig_gram(const float *w9, float *out9, float *det);
+void oracle_eig_scale_and_inverse(float l_conv, const float *a9, float *l2w9, float *w2l9);
+void oracle_eig_invcov_scale(const float *m9, float globalScale, float localScale, int isCov, float *out9);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

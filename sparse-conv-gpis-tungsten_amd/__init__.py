@@ -1,0 +1,13 @@
+"""MI355X-native sparse-convolution GPIS hot path (gfx950).
+
+The product is the C-ABI shared library built from ``csrc/`` (``libgpis_hip.so``, declared in
+``include/gpis.h``) plus the C++ ``Medium``-shaped host adapter in ``host/``.  This Python
+package is only glue for tests and ``bench.py``: numpy mirrors of the POD structs and a ctypes
+loader.  It never imports anything from ``oracle/`` and has no CPU fallback: if the HIP
+library is missing or no GPU is present, the calls fail loudly.
+"""
+from .bindings import (  # noqa: F401
+    GpisLib, Medium, load_library, library_path,
+    PARAMS, MEAN, RAY_IN, SEG_OUT, COND_COEFF, QUERY, NEE_QUERY, DERIVED, SCENE_S,
+    default_params, params_for_config, CTX, SCHEME, MEAN_TYPE,
+)

@@ -1,0 +1,331 @@
+"""ctypes / numpy mirror of include/gpis.h (ABI version 1).
+
+Struct layouts are checked against the C sizes at import time of the library
+(``gpis_abi_sizes``) so a drift between this file and the header fails loudly.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class CTX:
+    GLOBAL, RENEWAL_PLUS, RENEWAL, NONE = 0, 1, 2, 3
+
+
+class SCHEME:
+    UNI, NEE, MIS = 0, 1, 2
+
+
+class MEAN_TYPE:
+    HOMOGENEOUS, SPHERICAL, LINEAR = 0, 1, 2
+
+
+MEAN = np.dtype([
+    ("type", "<i4"), ("radius", "<f4"), ("offset", "<f4"), ("scale", "<f4"), ("min", "<f4"), ("_pad", "<i4"),
+    ("center", "<f8", 3), ("dir", "<f8", 3),
+], align=True)
+
+PARAMS = np.dtype([
+    ("abi_version", "<u4"),
+    ("step_size", "<f4"), ("min_step", "<u4"), ("seed", "<u4"), ("impulse_density", "<f4"),
+    ("single_realization", "<i4"), ("isotropic_3d_sampling", "<i4"), ("sampling_1d", "<i4"),
+    ("scheme_1d", "<i4"), ("correlation_xy", "<i4"), ("surf_vol_phase_separate", "<i4"),
+    ("surf_vol_phase_amp_thresh", "<f4"),
+    ("correlation_context", "<i4"), ("max_bounces", "<i4"),
+    ("sigma_a", "<f4", 3), ("sigma_s", "<f4", 3), ("density", "<f4"),
+    ("sigma", "<f4"), ("length_scale", "<f4"), ("aniso", "<f4", 3), ("use_aniso_mtx", "<i4"),
+    ("aniso_mtx", "<f4", 9), ("local_scale", "<f4"),
+    ("nonstationary", "<i4"), ("multi_resolution_grid", "<i4"), ("ls_ramp_type", "<i4"), ("_pad0", "<i4"),
+    ("ls_min", "<f8"), ("ls_max", "<f8"), ("ls_start", "<f8"), ("ls_end", "<f8"),
+    ("mean", MEAN), ("has_mean_additional", "<i4"), ("_pad1", "<i4"), ("mean_additional", MEAN),
+], align=True)
+
+RAY_IN = np.dtype([
+    ("pos", "<f4", 3), ("dir", "<f4", 3), ("near_t", "<f4"), ("far_t", "<f4"),
+    ("pixel", "<u4", 2), ("spp", "<u4"), ("segment", "<u4"),
+    ("scene_seed", "<u4"), ("info_t", "<f4"), ("u_jitter", "<f4"), ("first_scatter", "<u4"),
+    ("bounce", "<i4"), ("last_val", "<f4"), ("last_gp_id", "<i4"), ("_pad", "<i4"),
+    ("last_aniso", "<f8", 3), ("_reserved", "<f8", 3),
+], align=True)
+
+SEG_OUT = np.dtype([
+    ("t", "<f8"), ("aniso", "<f8", 3),
+    ("sample_t", "<f4"), ("continued_t", "<f4"), ("weight", "<f4", 3), ("continued_weight", "<f4", 3),
+    ("p", "<f4", 3), ("last_val", "<f4"), ("exited", "<i4"), ("ok", "<i4"), ("gp_id", "<i4"), ("scheme", "<i4"),
+], align=True)
+
+COND_COEFF = np.dtype([
+    ("value_scale", "<f4"), ("gradient_scale", "<f4", 3), ("ray_origin", "<f4", 3), ("n_evals", "<u4"),
+], align=True)
+
+QUERY = np.dtype([
+    ("p", "<f4", 3), ("dir", "<f4", 3), ("t_segment", "<f4"), ("info_t", "<f4"),
+    ("pixel", "<u4", 2), ("spp", "<u4"), ("segment", "<u4"),
+    ("scene_seed", "<u4"), ("_pad", "<u4", 3),
+    ("coeff", COND_COEFF),
+], align=True)
+
+NEE_QUERY = np.dtype([
+    ("ray_dir", "<f4", 3), ("normal", "<f4", 3), ("p", "<f4", 3), ("t_segment", "<f4"), ("info_t", "<f4"),
+    ("pixel", "<u4", 2), ("spp", "<u4"), ("segment", "<u4"), ("scene_seed", "<u4"),
+    ("coeff", COND_COEFF),
+], align=True)
+
+DERIVED = np.dtype([
+    ("world_to_local", "<f4", 9), ("local_to_world", "<f4", 9),
+    ("kernel_radius_world", "<f4"), ("kernel_radius_iso", "<f4"),
+    ("norm3d_world", "<f4"), ("norm3d_iso", "<f4"), ("norm1d", "<f4"),
+    ("impulses_per_cell", "<u4"), ("activate_conditioning", "<i4"), ("effective_scheme_1d", "<i4"),
+    ("multi_resolution", "<i4"), ("fast_path", "<i4"),
+], align=True)
+
+SCENE_S = np.dtype([
+    ("width", "<u4"), ("height", "<u4"), ("spp_begin", "<u4"), ("spp_count", "<u4"),
+    ("scene_seed", "<u4"), ("tile_size", "<u4"),
+    ("cam_pos", "<f4", 3), ("cam_fov_deg", "<f4"), ("bound_radius", "<f4"),
+    ("light_dir", "<f4", 3), ("light_radiance", "<f4"),
+    ("y_begin", "<u4"), ("y_count", "<u4"),
+], align=True)
+
+_EXPECTED_SIZES = {
+    "gpis_params": PARAMS.itemsize, "gpis_mean": MEAN.itemsize, "gpis_ray_in": RAY_IN.itemsize,
+    "gpis_seg_out": SEG_OUT.itemsize, "gpis_cond_coeff": COND_COEFF.itemsize, "gpis_query": QUERY.itemsize,
+    "gpis_nee_query": NEE_QUERY.itemsize, "gpis_derived": DERIVED.itemsize, "gpis_scene_s": SCENE_S.itemsize,
+}
+assert RAY_IN.itemsize == 128 and SEG_OUT.itemsize == 96 and COND_COEFF.itemsize == 32
+assert QUERY.itemsize == 96 and NEE_QUERY.itemsize == 96
+
+
+def default_params():
+    """Reference defaults (SCNM.cpp:17-34, GPM.cpp:86-95, GPF.hpp:1729,1784) as a PARAMS record."""
+    p = np.zeros((), dtype=PARAMS)
+    p["abi_version"] = 1
+    p["step_size"] = 0.01
+    p["min_step"] = 8
+    p["impulse_density"] = 3.0
+    p["correlation_context"] = CTX.RENEWAL_PLUS
+    p["max_bounces"] = 1024
+    p["density"] = 1.0
+    p["sigma"] = 1.0
+    p["length_scale"] = 1.0
+    p["aniso"] = 1.0
+    p["aniso_mtx"] = np.eye(3, dtype=np.float32).ravel()
+    p["local_scale"] = 3.0
+    p["ls_min"], p["ls_max"], p["ls_start"], p["ls_end"] = 1.0, 500.0, 0.0, 1.0
+    for key in ("mean", "mean_additional"):
+        p[key]["type"] = MEAN_TYPE.SPHERICAL
+        p[key]["radius"] = 1.0
+        p[key]["scale"] = 1.0
+        p[key]["min"] = -np.finfo(np.float32).max
+        p[key]["dir"] = (1.0, 0.0, 0.0)
+    return p
+
+
+def params_for_config(name):
+    """Scene-S medium parameters of the BASELINE.json configs."""
+    p = default_params()
+    p["sigma_a"] = 0.0
+    p["sigma_s"] = 1.0
+    p["density"] = 1.0
+    p["step_size"] = 0.01
+    p["min_step"] = 8
+    p["seed"] = 7
+    p["max_bounces"] = 1024
+    p["sigma"] = 0.1
+    p["length_scale"] = 0.05
+    p["aniso"] = 1.0
+    p["local_scale"] = 3.0
+    p["mean"]["type"] = MEAN_TYPE.SPHERICAL
+    p["mean"]["center"] = 0.0
+    p["mean"]["radius"] = 1.0
+    name = name.upper()
+    if name == "C0":      # CPU-reference config: world space, rho=8, ctx none, single realization
+        p["impulse_density"] = 8
+        p["correlation_context"] = CTX.NONE
+        p["single_realization"] = 1
+        p["isotropic_3d_sampling"] = 0
+    elif name == "C1":    # headline config: 3D isotropic, rho=32, renewal, single realization
+        p["impulse_density"] = 32
+        p["correlation_context"] = CTX.RENEWAL
+        p["single_realization"] = 1
+        p["isotropic_3d_sampling"] = 1
+    elif name == "C2":    # 1D sampling, MIS, Renewal+, correlationXY, per-path realizations
+        p["impulse_density"] = 32
+        p["correlation_context"] = CTX.RENEWAL_PLUS
+        p["single_realization"] = 0
+        p["isotropic_3d_sampling"] = 1
+        p["sampling_1d"] = 1
+        p["scheme_1d"] = SCHEME.MIS
+        p["correlation_xy"] = 1
+    elif name == "C3":    # multi-resolution non-stationary, rho=64, ensemble
+        p["impulse_density"] = 64
+        p["correlation_context"] = CTX.RENEWAL
+        p["single_realization"] = 0
+        p["isotropic_3d_sampling"] = 1
+        p["nonstationary"] = 1
+        p["multi_resolution_grid"] = 1
+        p["ls_ramp_type"] = 0
+        p["ls_min"], p["ls_max"], p["ls_start"], p["ls_end"] = 0.5, 2.0, -1.0, 1.0
+    else:
+        raise ValueError("unknown config %r" % name)
+    return p
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "libgpis_hip.so")
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    return ctypes.c_void_p(int(a))   # raw device address (e.g. torch tensor.data_ptr())
+
+
+class GpisLib:
+    """Thin ctypes view of libgpis_hip.so.  Raises if the library is absent (no CPU fallback)."""
+
+    SYMBOLS = [
+        "gpis_create", "gpis_destroy", "gpis_get_derived", "gpis_last_error", "gpis_default_params",
+        "gpis_sample_distance_batch", "gpis_transmittance_batch", "gpis_eval_value_batch",
+        "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
+        "gpis_xxhash32_batch", "gpis_pcg32_stream_batch",
+        "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
+        "gpis_get_counters", "gpis_reset_counters", "gpis_default_scene_s", "gpis_render_scene_s",
+    ]
+
+    def __init__(self, path=None):
+        path = path or library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        L.gpis_last_error.restype = ctypes.c_char_p
+        for name in self.SYMBOLS:
+            getattr(L, name)   # AttributeError if a declared symbol is not exported
+        vp, sz, i32, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
+        L.gpis_create.argtypes = [vp, i32, ctypes.POINTER(vp)]
+        L.gpis_destroy.argtypes = [vp]
+        L.gpis_get_derived.argtypes = [vp, vp]
+        L.gpis_default_params.argtypes = [vp]
+        L.gpis_default_params.restype = None
+        L.gpis_sample_distance_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+        L.gpis_transmittance_batch.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_eval_value_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+        L.gpis_eval_gradient_batch.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_conditioning_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+        L.gpis_nee_pdf_batch.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_nee_grad_batch.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_xxhash32_batch.argtypes = [vp, sz, i32, vp, vp, vp]
+        L.gpis_pcg32_stream_batch.argtypes = [vp, sz, vp, u32, vp, vp]
+        L.gpis_sample_distance_host.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_transmittance_host.argtypes = [vp, sz, vp, vp]
+        L.gpis_eval_value_host.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_eval_gradient_host.argtypes = [vp, sz, vp, vp]
+        L.gpis_get_counters.argtypes = [vp, vp, vp]
+        L.gpis_reset_counters.argtypes = [vp]
+        L.gpis_default_scene_s.argtypes = [vp, u32, u32, u32]
+        L.gpis_default_scene_s.restype = None
+        L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
+        if hasattr(L, "gpis_abi_sizes"):
+            L.gpis_abi_sizes.restype = ctypes.c_char_p
+            got = dict(kv.split("=") for kv in L.gpis_abi_sizes().decode().split(","))
+            for k, v in _EXPECTED_SIZES.items():
+                if int(got[k]) != v:
+                    raise RuntimeError("ABI drift: %s is %s bytes in C, %d in bindings.py" % (k, got[k], v))
+
+    def last_error(self):
+        return self.lib.gpis_last_error().decode(errors="replace")
+
+    def check(self, status, what):
+        if status != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, status, self.last_error()))
+
+
+_LIB = None
+
+
+def load_library(path=None):
+    global _LIB
+    if _LIB is None or (path and _LIB.path != path):
+        _LIB = GpisLib(path)
+    return _LIB
+
+
+class Medium:
+    """gpis_medium handle + the host-pointer convenience calls (numpy in / numpy out)."""
+
+    def __init__(self, params, device=0, lib=None):
+        self.L = lib or load_library()
+        self.params = np.array(params, dtype=PARAMS)
+        h = ctypes.c_void_p()
+        st = self.L.lib.gpis_create(_ptr(self.params), int(device), ctypes.byref(h))
+        self.L.check(st, "gpis_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.lib.gpis_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def derived(self):
+        d = np.zeros((), dtype=DERIVED)
+        self.L.check(self.L.lib.gpis_get_derived(self.h, _ptr(d)), "gpis_get_derived")
+        return d
+
+    # ---- host-pointer entries --------------------------------------------------------
+    def sample_distance(self, rays, want_coeff=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_IN)
+        out = np.zeros(rays.shape[0], dtype=SEG_OUT)
+        coeff = np.zeros(rays.shape[0], dtype=COND_COEFF) if want_coeff else None
+        st = self.L.lib.gpis_sample_distance_host(self.h, rays.shape[0], _ptr(rays), _ptr(out), _ptr(coeff))
+        self.L.check(st, "gpis_sample_distance_host")
+        return (out, coeff) if want_coeff else out
+
+    def transmittance(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_IN)
+        vis = np.zeros(rays.shape[0], dtype=np.uint8)
+        self.L.check(self.L.lib.gpis_transmittance_host(self.h, rays.shape[0], _ptr(rays), _ptr(vis)),
+                     "gpis_transmittance_host")
+        return vis
+
+    def eval_value(self, q):
+        q = np.ascontiguousarray(q, dtype=QUERY)
+        val = np.zeros(q.shape[0], dtype=np.float32)
+        gid = np.zeros(q.shape[0], dtype=np.int32)
+        self.L.check(self.L.lib.gpis_eval_value_host(self.h, q.shape[0], _ptr(q), _ptr(val), _ptr(gid)),
+                     "gpis_eval_value_host")
+        return val, gid
+
+    def eval_gradient(self, q):
+        q = np.ascontiguousarray(q, dtype=QUERY)
+        g = np.zeros((q.shape[0], 3), dtype=np.float32)
+        self.L.check(self.L.lib.gpis_eval_gradient_host(self.h, q.shape[0], _ptr(q), _ptr(g)),
+                     "gpis_eval_gradient_host")
+        return g
+
+    def counters(self):
+        e = ctypes.c_uint64()
+        s = ctypes.c_uint64()
+        self.L.check(self.L.lib.gpis_get_counters(self.h, ctypes.byref(e), ctypes.byref(s)), "gpis_get_counters")
+        return e.value, s.value
+
+    def reset_counters(self):
+        self.L.check(self.L.lib.gpis_reset_counters(self.h), "gpis_reset_counters")
+
+    # ---- device-pointer entries (raw addresses, e.g. torch tensors) ------------------
+    def call(self, name, *args):
+        fn = getattr(self.L.lib, name)
+        conv = [(_ptr(a) if (a is None or isinstance(a, np.ndarray)) else a) for a in args]
+        self.L.check(fn(self.h, *conv), name)
