@@ -1,0 +1,896 @@
+// gpis_hip.hip — kernels and C ABI (include/gpis.h) of the MI355X sparse-convolution GPIS path.
+//
+// Build (see __graft_entry__.build):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -I include -o libgpis_hip.so gpis_hip.hip
+//
+// Layout in HBM: rays and results are arrays of the 128-/96-byte PODs of gpis.h (a wave reads
+// 64 consecutive records = 8 KiB / 6 KiB contiguous); the medium's constants live in one
+// DevModel block read through scalar loads; counters are two 64-bit words updated once per wave.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "gpis.h"
+#include "gpis_device.hpp"
+#include "gpis_fast.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace gpis;
+
+// ======================================================================================
+// errors
+// ======================================================================================
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_err(GPIS_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *gpis_last_error(void) { return g_err; }
+
+// ======================================================================================
+// handle
+// ======================================================================================
+struct SceneConst {   // host-precomputed scene-S constants (host libm: tanf, normalisation)
+    gpis_scene_s s;
+    float plane_dist, ratio, psx;
+    float light[3];
+};
+
+struct gpis_medium {
+    gpis_params params;
+    DevModel host_model;
+    gpis_derived derived;
+    int device;
+    DevModel *d_model;
+    Counters *d_counters;
+    FastTable fast;          // single-realization cell table (gpis_fast.hpp); cells == nullptr when unused
+    // staging for the *_host entries and workspace for the renderer (grown on demand)
+    void *stage[4];
+    size_t stage_bytes[4];
+    std::mutex mu;
+};
+
+static int ensure_stage(gpis_medium *m, int slot, size_t bytes)
+{
+    if (m->stage_bytes[slot] >= bytes)
+        return GPIS_OK;
+    if (m->stage[slot])
+        HIP_TRY(hipFree(m->stage[slot]));
+    m->stage[slot] = nullptr;
+    m->stage_bytes[slot] = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&m->stage[slot], want));
+    m->stage_bytes[slot] = want;
+    return GPIS_OK;
+}
+
+// ======================================================================================
+// host-side "fromJson": precompute the constants the reference computes once
+// (GPF.cpp:654-679, 696-709, 741-760; SCN.cpp:8-37; GPM.cpp:152-158)
+// ======================================================================================
+static inline float hsum3e(float a, float b, float c) { return a + (b + c); }
+#define HM(m, r, c) ((m)[3 * (r) + (c)])
+static float hcof(const float *m, int i, int j)
+{
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return HM(m, i1, j1) * HM(m, i2, j2) - HM(m, i1, j2) * HM(m, i2, j1);
+}
+static void hinverse3(const float *m, float *r)
+{
+    float c0 = hcof(m, 0, 0), c1 = hcof(m, 1, 0), c2 = hcof(m, 2, 0);
+    float det = hsum3e(c0 * HM(m, 0, 0), c1 * HM(m, 1, 0), c2 * HM(m, 2, 0));
+    float invdet = 1.0f / det;
+    HM(r, 1, 0) = hcof(m, 0, 1) * invdet; HM(r, 1, 1) = hcof(m, 1, 1) * invdet; HM(r, 2, 0) = hcof(m, 0, 2) * invdet;
+    HM(r, 1, 2) = hcof(m, 2, 1) * invdet; HM(r, 2, 1) = hcof(m, 1, 2) * invdet; HM(r, 2, 2) = hcof(m, 2, 2) * invdet;
+    HM(r, 0, 0) = c0 * invdet; HM(r, 0, 1) = c1 * invdet; HM(r, 0, 2) = c2 * invdet;
+}
+static float hdet3(const float *m)
+{
+    auto h = [&](int a, int b, int c) { return HM(m, 0, a) * (HM(m, 1, b) * HM(m, 2, c) - HM(m, 1, c) * HM(m, 2, b)); };
+    return h(0, 1, 2) - h(1, 0, 2) + h(2, 0, 1);
+}
+
+static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
+{
+    memset(&M, 0, sizeof M);
+    memset(&D, 0, sizeof D);
+    M.single_realization = P.single_realization != 0;
+    M.iso3d = P.isotropic_3d_sampling != 0;
+    M.sampling_1d = P.sampling_1d != 0;
+    M.correlation_xy = P.correlation_xy != 0;
+    M.ctx = P.correlation_context;
+    M.activate_conditioning = !M.single_realization && (M.ctx == GPIS_CTX_RENEWAL || M.ctx == GPIS_CTX_RENEWAL_PLUS);
+    M.scheme_1d_eff = (!M.single_realization && M.sampling_1d) ? P.scheme_1d : GPIS_UNI;
+    M.nonstationary = P.nonstationary != 0;
+    M.multi_resolution_grid = P.multi_resolution_grid != 0;
+    M.multi_res = M.nonstationary && M.multi_resolution_grid;
+    M.use_aniso_mtx = P.use_aniso_mtx != 0;
+    M.surf_vol_phase_separate = P.surf_vol_phase_separate != 0;
+    M.surf_vol_phase_amp_thresh = P.surf_vol_phase_amp_thresh;
+    M.has_mean_additional = P.has_mean_additional != 0;
+    M.max_bounces = P.max_bounces;
+    M.seed = P.seed;
+    M.n_impulses = (uint32_t)P.impulse_density;
+    M.min_step = P.min_step;
+    M.step_size = P.step_size;
+    M.impulse_density = P.impulse_density;
+    M.sigma = M.nonstationary ? (float)(1.0 * (double)P.sigma) : P.sigma;
+
+    // SquaredExponentialCovariance::fromJson
+    float l_conv = P.length_scale * sqrtf(2.f) / 2;
+    float l2w[9] = {0}, w2l[9] = {0};
+    float l_aniso[3] = {0, 0, 0};
+    if (!M.use_aniso_mtx) {
+        for (int i = 0; i < 3; ++i) {
+            l_aniso[i] = l_conv * P.aniso[i];
+            float inv = 1.0f / l_aniso[i];
+            if (std::isinf(inv) || std::isnan(inv)) inv = 0;
+            HM(l2w, i, i) = l_aniso[i];
+            HM(w2l, i, i) = inv;
+            HM(M.invcov_world, i, i) = inv * inv;
+        }
+        M.cov_det_sqrt_world = (double)(l_aniso[0] * l_aniso[1] * l_aniso[2]);
+        float a = l_aniso[0] > l_aniso[1] ? l_aniso[0] : l_aniso[1];
+        M.mtx_factor = a > l_aniso[2] ? a : l_aniso[2];
+    } else {
+        for (int i = 0; i < 9; ++i) l2w[i] = l_conv * P.aniso_mtx[i];
+        hinverse3(l2w, w2l);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                HM(M.invcov_world, r, c) = hsum3e(HM(w2l, 0, r) * HM(w2l, 0, c), HM(w2l, 1, r) * HM(w2l, 1, c), HM(w2l, 2, r) * HM(w2l, 2, c));
+        float det = hdet3(M.invcov_world);
+        M.cov_det_sqrt_world = 1.0 / (double)sqrtf(det);
+        float e0 = (HM(l2w, 0, 0) + HM(l2w, 0, 1)) + HM(l2w, 0, 2);
+        float e1 = (HM(l2w, 1, 0) + HM(l2w, 1, 1)) + HM(l2w, 1, 2);
+        float e2 = (HM(l2w, 2, 0) + HM(l2w, 2, 1)) + HM(l2w, 2, 2);
+        float a = e0 > e1 ? e0 : e1;
+        M.mtx_factor = a > e2 ? a : e2;
+    }
+    memcpy(M.w2l, w2l, sizeof w2l);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            HM(M.w2l_T, r, c) = HM(w2l, c, r);
+            HM(M.l2w_T, r, c) = HM(l2w, c, r);
+        }
+    M.kernel_scale = P.local_scale;
+    M.pi_pow_1_5 = pow(M_PI, 1.5);
+    M.sqrt_pi = sqrt(M_PI);
+
+    // ramp + multi-resolution tables (host libm so that they equal the reference's values)
+    M.ls_ramp_type = P.ls_ramp_type;
+    M.ls_min = P.ls_min; M.ls_max = P.ls_max;
+    M.ls_scale = 1.0 / (P.ls_end - P.ls_start);
+    M.ls_offset = -P.ls_start * M.ls_scale;
+    { double mn = P.ls_min + 1., mx = P.ls_max + 1.; M.ls_log_min2 = log(mn * mn); M.ls_log_max2 = log(mx * mx); }
+    M.ls_maxval = (float)(P.ls_max > P.ls_min ? P.ls_max : P.ls_min);
+    const float base = 2.5f;
+    M.log_base = logf(base);
+    for (int l = kLevelMin; l <= kLevelMax; ++l) {
+        float sc = powf(base, (float)l);
+        M.level_scale[l - kLevelMin] = sc;
+        M.level_addseed[l - kLevelMin] = (int)floorf(logf(sc) / logf(base));
+    }
+    float wss = M.nonstationary ? M.ls_maxval : 1.f;
+    M.world_addseed = (int)floorf(logf(wss) / logf(base));
+
+    // stationary constants
+    auto variance3d = [&](float dens, float R, bool isIdentity, float globalScale, float localScale) {
+        double idua = dens / (R * R * R);
+        double cds = 1.0;
+        if (!isIdentity) {
+            cds = M.cov_det_sqrt_world;
+            cds *= pow(globalScale, 3);
+        }
+        cds *= pow(localScale, 3);
+        return (float)(idua * (M.pi_pow_1_5 * cds));
+    };
+    M.radius_iso = M.kernel_scale;
+    M.radius_world = M.kernel_scale * 1.0f * M.mtx_factor;
+    M.norm3d_world = sqrtf(variance3d(P.impulse_density, M.radius_world, false, 1.0f, 1.0f));
+    M.norm3d_iso = sqrtf(variance3d(P.impulse_density, M.radius_iso, true, 1.0f, 1.0f));
+    {
+        double idua = P.impulse_density / M.radius_iso;
+        M.norm1d = sqrtf((float)(idua * (M.sqrt_pi * 1.0f)));
+    }
+    // prepareForRender
+    bool all_zero = true;
+    for (int c = 0; c < 3; ++c) {
+        float sa = P.sigma_a[c] * P.density, ss = P.sigma_s[c] * P.density;
+        float st = sa + ss;
+        M.sigma_s_over_t[c] = ss / st;
+        if (ss != 0.0f) all_zero = false;
+    }
+    M.absorption_only = all_zero;
+    M.mean[0] = P.mean;
+    M.mean[1] = P.mean_additional;
+    for (int w = 0; w < 2; ++w) {
+        const gpis_mean &mu = M.mean[w];
+        double l2 = 0.; l2 += mu.dir[0] * mu.dir[0]; l2 += mu.dir[1] * mu.dir[1]; l2 += mu.dir[2] * mu.dir[2];
+        double len = sqrt(l2);
+        double inv = len > 0 ? 1.0 / len : 0.0;
+        for (int k = 0; k < 3; ++k) M.lin_dir[w][k] = mu.dir[k] * inv;
+    }
+
+    memcpy(D.world_to_local, w2l, sizeof w2l);
+    memcpy(D.local_to_world, l2w, sizeof l2w);
+    if (!M.nonstationary) {
+        D.kernel_radius_world = M.radius_world;
+        D.kernel_radius_iso = M.radius_iso;
+        D.norm3d_world = M.norm3d_world;
+        D.norm3d_iso = M.norm3d_iso;
+        D.norm1d = M.norm1d;
+    } else {
+        float ls = (float)((double)1.0f * (M.multi_resolution_grid ? 1.0 : (double)M.ls_maxval));
+        D.kernel_radius_world = M.kernel_scale * ls * M.mtx_factor;
+        D.kernel_radius_iso = M.kernel_scale;
+        float nss = M.multi_resolution_grid ? 1.0f : (float)0.f;   // position dependent when !multi_resolution_grid
+        (void)nss;
+        D.norm3d_world = 0.f; D.norm3d_iso = M.norm3d_iso; D.norm1d = 0.f;
+    }
+    D.impulses_per_cell = M.n_impulses;
+    D.activate_conditioning = M.activate_conditioning;
+    D.effective_scheme_1d = M.scheme_1d_eff;
+    D.multi_resolution = M.multi_res;
+    return GPIS_OK;
+}
+
+// ======================================================================================
+// kernels — generic path: one lane = one ray / query, impulses generated on the fly
+// ======================================================================================
+constexpr int kBlock = 64;   // one wave per workgroup: rays are independent, small blocks balance the march
+
+__device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t n_eval, uint32_t n_seg)
+{
+    // one pair of 64-bit atomics per wave
+    unsigned long long e = n_eval, s = n_seg;
+    for (int off = 32; off > 0; off >>= 1) {
+        e += __shfl_down(e, off, 64);
+        s += __shfl_down(s, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (e) atomicAdd(&cnt->n_eval, e);
+        if (s) atomicAdd(&cnt->n_seg, s);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sample_distance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+                                                            gpis_seg_out *__restrict__ out, gpis_cond_coeff *__restrict__ coeff,
+                                                            const uint8_t *__restrict__ mask, Counters *cnt)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const DevModel &M = *Mp;
+    Realization noise{};
+    uint32_t nseg = 0;
+    if (i < n && (!mask || mask[i])) {
+        gpis_ray_in ray = rays[i];
+        gpis_seg_out o;
+        sample_distance_one(M, noise, ray, o);
+        out[i] = o;
+        if (coeff) {
+            gpis_cond_coeff c = noise.c;
+            c.n_evals = noise.n_eval;
+            coeff[i] = c;
+        }
+        nseg = 1;
+    }
+    flush_counters(cnt, noise.n_eval, nseg);
+}
+
+__global__ void __launch_bounds__(kBlock) k_transmittance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+                                                          uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const DevModel &M = *Mp;
+    Realization noise{};
+    uint32_t nseg = 0;
+    if (i < n) {
+        if (!mask || mask[i]) {
+            gpis_ray_in ray = rays[i];
+            MediumState st;
+            state_from_ray(ray, st);
+            visible[i] = transmittance_one(M, noise, ray, st) ? 1 : 0;
+            nseg = 1;
+        } else {
+            visible[i] = 0;
+        }
+    }
+    flush_counters(cnt, noise.n_eval, nseg);
+}
+
+__device__ __forceinline__ RayInfo info_of(const gpis_query &q) { return RayInfo{q.pixel[0], q.pixel[1], q.spp, q.segment, q.scene_seed, q.info_t}; }
+__device__ __forceinline__ RayInfo info_of(const gpis_nee_query &q) { return RayInfo{q.pixel[0], q.pixel[1], q.spp, q.segment, q.scene_seed, q.info_t}; }
+
+__global__ void __launch_bounds__(kBlock) k_eval_value(const DevModel *__restrict__ Mp, size_t n, const gpis_query *__restrict__ q,
+                                                       float *__restrict__ value, int32_t *__restrict__ gp_id, Counters *cnt)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    Realization r{};
+    if (i < n) {
+        gpis_query qq = q[i];
+        r.c = qq.coeff;
+        int id;
+        value[i] = evaluate_value(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq), id);
+        if (gp_id) gp_id[i] = id;
+    }
+    flush_counters(cnt, r.n_eval, 0);
+}
+__global__ void __launch_bounds__(kBlock) k_eval_gradient(const DevModel *__restrict__ Mp, size_t n, const gpis_query *__restrict__ q,
+                                                          float *__restrict__ grad3, Counters *cnt)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    Realization r{};
+    if (i < n) {
+        gpis_query qq = q[i];
+        r.c = qq.coeff;
+        V3 g = evaluate_gradient(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), qq.t_segment, v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq));
+        grad3[3 * i] = g.x; grad3[3 * i + 1] = g.y; grad3[3 * i + 2] = g.z;
+    }
+    flush_counters(cnt, r.n_eval, 0);
+}
+__global__ void __launch_bounds__(kBlock) k_conditioning(const DevModel *__restrict__ Mp, size_t n, const gpis_query *__restrict__ q,
+                                                         const float *__restrict__ tv, const float *__restrict__ tg,
+                                                         gpis_cond_coeff *__restrict__ co, Counters *cnt)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    Realization r{};
+    if (i < n) {
+        gpis_query qq = q[i];
+        conditioning(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), tv[i], v3(tg[3 * i], tg[3 * i + 1], tg[3 * i + 2]), info_of(qq));
+        gpis_cond_coeff c = r.c;
+        c.n_evals = r.n_eval;
+        co[i] = c;
+    }
+    flush_counters(cnt, r.n_eval, 0);
+}
+__global__ void __launch_bounds__(kBlock) k_nee(const DevModel *__restrict__ Mp, size_t n, const gpis_nee_query *__restrict__ q,
+                                                float *__restrict__ pdf, float *__restrict__ grad3, Counters *cnt)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    Realization r{};
+    if (i < n) {
+        gpis_nee_query qq = q[i];
+        r.c = qq.coeff;
+        V3 rd = v3(qq.ray_dir[0], qq.ray_dir[1], qq.ray_dir[2]), nn = v3(qq.normal[0], qq.normal[1], qq.normal[2]), p = v3(qq.p[0], qq.p[1], qq.p[2]);
+        if (pdf) pdf[i] = nee_pdf(*Mp, r, rd, nn, p, qq.t_segment, info_of(qq));
+        if (grad3) {
+            V3 g = nee_grad(*Mp, r, rd, nn, p, info_of(qq));
+            grad3[3 * i] = g.x; grad3[3 * i + 1] = g.y; grad3[3 * i + 2] = g.z;
+        }
+    }
+    flush_counters(cnt, r.n_eval, 0);
+}
+__global__ void k_xxhash32(size_t n, int arity, const uint32_t *__restrict__ w, uint32_t *__restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *p = w + i * (size_t)arity;
+    out[i] = arity == 1 ? xxhash32_1(p[0]) : arity == 2 ? xxhash32_2(p[0], p[1]) : arity == 3 ? xxhash32_3(p[0], p[1], p[2]) : xxhash32_4(p[0], p[1], p[2], p[3]);
+}
+__global__ void k_pcg32_stream(size_t n, const uint64_t *__restrict__ state, uint32_t count, uint32_t *__restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pcg32 s;
+    s.set_state(state[i]);
+    for (uint32_t k = 0; k < count; ++k)
+        out[i * (size_t)count + k] = s.next_i();
+}
+
+// ======================================================================================
+// scene-S tile → ray-batch driver.  Sample index within a chunk:
+// ((y*W + x) * spp_count + k): the 64 lanes of a wave carry consecutive spp of one pixel.
+// ======================================================================================
+__device__ __forceinline__ bool sphere_chord(V3 o, V3 d, float R, float &t0, float &t1)
+{
+    double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+    double a = dx * dx + dy * dy + dz * dz;
+    double b = ox * dx + oy * dy + oz * dz;
+    double c = ox * ox + oy * oy + oz * oz - (double)R * (double)R;
+    double disc = b * b - a * c;
+    if (!(disc > 0.0))
+        return false;
+    double sq = sqrt(disc);
+    double ta = (-b - sq) / a, tb = (-b + sq) / a;
+    if (tb <= 0.0)
+        return false;
+    if (ta < 0.0) ta = 0.0;
+    t0 = (float)ta; t1 = (float)tb;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_scene_primary(SceneConst sc, size_t first_pixel, size_t n_samples,
+                                                       gpis_ray_in *__restrict__ rays, float *__restrict__ u_shadow, uint8_t *__restrict__ valid)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    const gpis_scene_s &s = sc.s;
+    size_t pix = first_pixel + i / s.spp_count;
+    uint32_t k = (uint32_t)(i % s.spp_count);
+    uint32_t x = (uint32_t)(pix % s.width), y = (uint32_t)(pix / s.width);
+    uint32_t spp = s.spp_begin + k;
+    Pcg32 g;
+    g.set_state((uint64_t)(uint32_t)(xxhash32_4(x, y, spp, s.scene_seed) + 1u));
+    float jx = normalized_uint(g.next_i()), jy = normalized_uint(g.next_i());
+    float u0 = normalized_uint(g.next_i()), u1 = normalized_uint(g.next_i());
+    V3 local = normalized(v3(-1.0f + ((float)x + jx) * 2.0f * sc.psx, sc.ratio - ((float)y + jy) * 2.0f * sc.psx, sc.plane_dist));
+    V3 d = v3(local.x, local.y, -local.z);
+    V3 o = v3(s.cam_pos[0], s.cam_pos[1], s.cam_pos[2]);
+    gpis_ray_in r;
+    memset(&r, 0, sizeof r);
+    r.pos[0] = o.x; r.pos[1] = o.y; r.pos[2] = o.z;
+    r.dir[0] = d.x; r.dir[1] = d.y; r.dir[2] = d.z;
+    r.pixel[0] = x; r.pixel[1] = y; r.spp = spp; r.segment = 0;
+    r.scene_seed = s.scene_seed; r.info_t = 0.f; r.u_jitter = u0;
+    r.first_scatter = 1;
+    float t0 = 0.f, t1 = 0.f;
+    bool hit = sphere_chord(o, d, s.bound_radius, t0, t1);
+    r.near_t = t0; r.far_t = t1;
+    rays[i] = r;
+    u_shadow[i] = u1;
+    valid[i] = hit ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_scene_shade(SceneConst sc, size_t n_samples, const gpis_ray_in *__restrict__ prim,
+                                                     const gpis_seg_out *__restrict__ seg, const float *__restrict__ u_shadow,
+                                                     const uint8_t *__restrict__ valid, gpis_ray_in *__restrict__ shadow,
+                                                     float *__restrict__ cosl, uint8_t *__restrict__ valid2, uint8_t *__restrict__ hit)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    uint8_t v2 = 0, h = 0;
+    float c = 0.f;
+    if (valid[i]) {
+        gpis_seg_out o = seg[i];
+        if (o.ok && !o.exited) {
+            h = 1;
+            V3 l = v3(sc.light[0], sc.light[1], sc.light[2]);
+            double ax = o.aniso[0], ay = o.aniso[1], az = o.aniso[2];
+            double len = sqrt(ax * ax + ay * ay + az * az);
+            V3 nn = v3((float)(ax / len), (float)(ay / len), (float)(az / len));
+            c = dot(nn, l);
+            float t0, t1;
+            if (c > 0.f && sphere_chord(v3(o.p[0], o.p[1], o.p[2]), l, sc.s.bound_radius, t0, t1)) {
+                gpis_ray_in p = prim[i];
+                gpis_ray_in sh;
+                memset(&sh, 0, sizeof sh);
+                sh.pos[0] = o.p[0]; sh.pos[1] = o.p[1]; sh.pos[2] = o.p[2];
+                sh.dir[0] = l.x; sh.dir[1] = l.y; sh.dir[2] = l.z;
+                sh.near_t = 0.f; sh.far_t = t1;
+                sh.pixel[0] = p.pixel[0]; sh.pixel[1] = p.pixel[1]; sh.spp = p.spp;
+                sh.segment = p.segment + 1;
+                sh.scene_seed = p.scene_seed;
+                sh.info_t = p.info_t + o.sample_t;
+                sh.u_jitter = u_shadow[i];
+                sh.first_scatter = 0;
+                sh.bounce = p.bounce + 1;
+                sh.last_val = o.last_val;
+                sh.last_gp_id = o.gp_id;
+                sh.last_aniso[0] = o.aniso[0]; sh.last_aniso[1] = o.aniso[1]; sh.last_aniso[2] = o.aniso[2];
+                shadow[i] = sh;
+                v2 = 1;
+            }
+        }
+    }
+    cosl[i] = c;
+    valid2[i] = v2;
+    hit[i] = h;
+}
+
+// one lane per pixel: sequential sum over its spp, in sample order (matches the CPU estimator)
+__global__ void __launch_bounds__(256) k_scene_accumulate(SceneConst sc, size_t first_pixel, size_t n_pixels, const float *__restrict__ cosl,
+                                                          const uint8_t *__restrict__ valid2, const uint8_t *__restrict__ vis,
+                                                          const uint8_t *__restrict__ hit, float *__restrict__ radiance_sum,
+                                                          uint32_t *__restrict__ hit_count)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pixels) return;
+    const uint32_t spp = sc.s.spp_count;
+    float acc = 0.f;
+    uint32_t hits = 0;
+    for (uint32_t k = 0; k < spp; ++k) {
+        size_t i = j * spp + k;
+        hits += hit[i];
+        if (valid2[i])
+            acc += cosl[i] * (vis[i] ? 1.f : 0.f) * sc.s.light_radiance;
+    }
+    radiance_sum[first_pixel + j] += acc;
+    if (hit_count) hit_count[first_pixel + j] += hits;
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+static inline unsigned grid_of(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+extern "C" const char *gpis_abi_sizes(void)
+{
+    static char buf[512];
+    snprintf(buf, sizeof buf,
+             "gpis_params=%zu,gpis_mean=%zu,gpis_ray_in=%zu,gpis_seg_out=%zu,gpis_cond_coeff=%zu,gpis_query=%zu,"
+             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu",
+             sizeof(gpis_params), sizeof(gpis_mean), sizeof(gpis_ray_in), sizeof(gpis_seg_out), sizeof(gpis_cond_coeff),
+             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s));
+    return buf;
+}
+
+extern "C" void gpis_default_params(gpis_params *p)
+{
+    memset(p, 0, sizeof *p);
+    p->abi_version = GPIS_ABI_VERSION;
+    p->step_size = 0.01f; p->min_step = 8; p->seed = 0; p->impulse_density = 3.0f;
+    p->scheme_1d = GPIS_UNI;
+    p->correlation_context = GPIS_CTX_RENEWAL_PLUS;
+    p->max_bounces = 1024;
+    p->density = 1.f;
+    p->sigma = 1.f; p->length_scale = 1.f;
+    p->aniso[0] = p->aniso[1] = p->aniso[2] = 1.f;
+    p->aniso_mtx[0] = p->aniso_mtx[4] = p->aniso_mtx[8] = 1.f;
+    p->local_scale = 3.0f;
+    p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;
+    p->mean.type = GPIS_MEAN_SPHERICAL; p->mean.radius = 1.f;
+    p->mean.scale = 1.f; p->mean.min = -FLT_MAX; p->mean.dir[0] = 1.;
+    p->mean_additional = p->mean;
+}
+
+extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **out)
+{
+    if (!params || !out) return set_err(GPIS_ERR_INVALID_ARG, "gpis_create: null argument");
+    if (params->abi_version != GPIS_ABI_VERSION) return set_err(GPIS_ERR_INVALID_ARG, "gpis_create: abi_version %u != %d", params->abi_version, GPIS_ABI_VERSION);
+    // same failure points as the reference's JSON parsing (GPM.cpp:40, SCNM.cpp:44)
+    if (params->correlation_context < 0 || params->correlation_context > 3) return set_err(GPIS_ERR_INVALID_ARG, "Invalid correlation context: '%d'", params->correlation_context);
+    if (params->scheme_1d < 0 || params->scheme_1d > 2) return set_err(GPIS_ERR_INVALID_ARG, "Invalid sparse conv sampling scheme: '%d'", params->scheme_1d);
+    if (!(params->impulse_density >= 0.f) || params->impulse_density > 4096.f) return set_err(GPIS_ERR_INVALID_ARG, "impulse_density out of range");
+    if (params->mean.type < 0 || params->mean.type > 2 || (params->has_mean_additional && (params->mean_additional.type < 0 || params->mean_additional.type > 2)))
+        return set_err(GPIS_ERR_INVALID_ARG, "invalid mean type");
+    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > 2)) return set_err(GPIS_ERR_INVALID_ARG, "invalid ls ramp type");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return set_err(GPIS_ERR_NO_DEVICE, "gpis_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= count) return set_err(GPIS_ERR_INVALID_ARG, "gpis_create: device %d out of range (%d devices)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return set_err(GPIS_ERR_NO_DEVICE, "gpis_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+    gpis_medium *m = new (std::nothrow) gpis_medium();
+    if (!m) return set_err(GPIS_ERR_DEVICE, "out of host memory");
+    m->params = *params;
+    m->device = device;
+    for (int i = 0; i < 4; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
+    m->d_model = nullptr; m->d_counters = nullptr;
+    memset(&m->fast, 0, sizeof m->fast);
+    int st = build_model(*params, m->host_model, m->derived);
+    if (st != GPIS_OK) { delete m; return st; }
+    hipError_t e = hipMalloc(&m->d_model, sizeof(DevModel));
+    if (e == hipSuccess) e = hipMalloc(&m->d_counters, sizeof(Counters));
+    if (e == hipSuccess) e = hipMemcpy(m->d_model, &m->host_model, sizeof(DevModel), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(m->d_counters, 0, sizeof(Counters));
+    if (e != hipSuccess) {
+        set_err(GPIS_ERR_DEVICE, "gpis_create: %s", hipGetErrorString(e));
+        if (m->d_model) (void)hipFree(m->d_model);
+        if (m->d_counters) (void)hipFree(m->d_counters);
+        delete m;
+        return GPIS_ERR_DEVICE;
+    }
+    st = fast_table_build(m->host_model, m->d_model, &m->fast);
+    if (st != GPIS_OK) {
+        set_err(st, "gpis_create: building the cell table failed");
+        (void)hipFree(m->d_model); (void)hipFree(m->d_counters);
+        delete m;
+        return st;
+    }
+    m->derived.fast_path = m->fast.cells != nullptr;
+    *out = m;
+    return GPIS_OK;
+}
+
+extern "C" int gpis_destroy(gpis_medium *m)
+{
+    if (!m) return GPIS_OK;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    fast_table_free(&m->fast);
+    for (int i = 0; i < 4; ++i)
+        if (m->stage[i]) (void)hipFree(m->stage[i]);
+    if (m->d_model) (void)hipFree(m->d_model);
+    if (m->d_counters) (void)hipFree(m->d_counters);
+    delete m;
+    return GPIS_OK;
+}
+
+extern "C" int gpis_get_derived(const gpis_medium *m, gpis_derived *out)
+{
+    if (!m || !out) return set_err(GPIS_ERR_INVALID_ARG, "null argument");
+    *out = m->derived;
+    return GPIS_OK;
+}
+
+#define CHECK_ARGS(cond)                                                        \
+    do {                                                                        \
+        if (!(cond)) return set_err(GPIS_ERR_INVALID_ARG, "%s: invalid argument (%s)", __func__, #cond); \
+    } while (0)
+
+static int launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return set_err(GPIS_ERR_DEVICE, "%s launch: %s", what, hipGetErrorString(e));
+    return GPIS_OK;
+}
+
+static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff,
+                                const uint8_t *mask, hipStream_t s)
+{
+    if (n == 0) return GPIS_OK;
+    if (m->fast.cells && fast_supported(m->host_model)) {
+        int st = fast_sample_distance(m->d_model, &m->fast, n, rays, out, coeff, mask, m->d_counters, s);
+        if (st != GPIS_OK) return set_err(st, "fast sample_distance launch failed");
+        return launch_check("k_fast_sample_distance");
+    }
+    k_sample_distance<<<grid_of(n, kBlock), kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
+    return launch_check("k_sample_distance");
+}
+static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible, const uint8_t *mask, hipStream_t s)
+{
+    if (n == 0) return GPIS_OK;
+    if (m->fast.cells && fast_supported(m->host_model)) {
+        int st = fast_transmittance(m->d_model, &m->fast, n, rays, visible, mask, m->d_counters, s);
+        if (st != GPIS_OK) return set_err(st, "fast transmittance launch failed");
+        return launch_check("k_fast_transmittance");
+    }
+    k_transmittance<<<grid_of(n, kBlock), kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters);
+    return launch_check("k_transmittance");
+}
+
+extern "C" int gpis_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && out)));
+    HIP_TRY(hipSetDevice(m->device));
+    return sample_distance_impl(m, n, rays, out, coeff, nullptr, (hipStream_t)stream);
+}
+extern "C" int gpis_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && visible)));
+    HIP_TRY(hipSetDevice(m->device));
+    return transmittance_impl(m, n, rays, visible, nullptr, (hipStream_t)stream);
+}
+extern "C" int gpis_eval_value_batch(gpis_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (q && value)));
+    if (n == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_eval_value<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, value, gp_id, m->d_counters);
+    return launch_check("k_eval_value");
+}
+extern "C" int gpis_eval_gradient_batch(gpis_medium *m, size_t n, const gpis_query *q, float *grad3, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (q && grad3)));
+    if (n == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_eval_gradient<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, grad3, m->d_counters);
+    return launch_check("k_eval_gradient");
+}
+extern "C" int gpis_conditioning_batch(gpis_medium *m, size_t n, const gpis_query *q, const float *target_val, const float *target_grad3,
+                                       gpis_cond_coeff *coeff_out, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (q && target_val && target_grad3 && coeff_out)));
+    if (n == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_conditioning<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, target_val, target_grad3, coeff_out, m->d_counters);
+    return launch_check("k_conditioning");
+}
+extern "C" int gpis_nee_pdf_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *pdf, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (q && pdf)));
+    if (n == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_nee<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, pdf, nullptr, m->d_counters);
+    return launch_check("k_nee");
+}
+extern "C" int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *grad3, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (q && grad3)));
+    if (n == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_nee<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, nullptr, grad3, m->d_counters);
+    return launch_check("k_nee");
+}
+extern "C" int gpis_xxhash32_batch(gpis_medium *m, size_t n, int arity, const uint32_t *words, uint32_t *out, void *stream)
+{
+    CHECK_ARGS(m && arity >= 1 && arity <= 4 && (n == 0 || (words && out)));
+    if (n == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_xxhash32<<<grid_of(n, 256), 256, 0, (hipStream_t)stream>>>(n, arity, words, out);
+    return launch_check("k_xxhash32");
+}
+extern "C" int gpis_pcg32_stream_batch(gpis_medium *m, size_t n, const uint64_t *state, uint32_t count, uint32_t *out, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (state && out)));
+    if (n == 0 || count == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_pcg32_stream<<<grid_of(n, 256), 256, 0, (hipStream_t)stream>>>(n, state, count, out);
+    return launch_check("k_pcg32_stream");
+}
+
+// ---- host-pointer conveniences -----------------------------------------------------------
+extern "C" int gpis_sample_distance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && out)));
+    if (n == 0) return GPIS_OK;
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    int st;
+    if ((st = ensure_stage(m, 0, n * sizeof(gpis_ray_in))) || (st = ensure_stage(m, 1, n * sizeof(gpis_seg_out))) ||
+        (st = ensure_stage(m, 2, n * sizeof(gpis_cond_coeff))))
+        return st;
+    HIP_TRY(hipMemcpy(m->stage[0], rays, n * sizeof(gpis_ray_in), hipMemcpyHostToDevice));
+    st = sample_distance_impl(m, n, (const gpis_ray_in *)m->stage[0], (gpis_seg_out *)m->stage[1],
+                              coeff ? (gpis_cond_coeff *)m->stage[2] : nullptr, nullptr, nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, m->stage[1], n * sizeof(gpis_seg_out), hipMemcpyDeviceToHost));
+    if (coeff) HIP_TRY(hipMemcpy(coeff, m->stage[2], n * sizeof(gpis_cond_coeff), hipMemcpyDeviceToHost));
+    return GPIS_OK;
+}
+extern "C" int gpis_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && visible)));
+    if (n == 0) return GPIS_OK;
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    int st;
+    if ((st = ensure_stage(m, 0, n * sizeof(gpis_ray_in))) || (st = ensure_stage(m, 1, n)))
+        return st;
+    HIP_TRY(hipMemcpy(m->stage[0], rays, n * sizeof(gpis_ray_in), hipMemcpyHostToDevice));
+    st = transmittance_impl(m, n, (const gpis_ray_in *)m->stage[0], (uint8_t *)m->stage[1], nullptr, nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(visible, m->stage[1], n, hipMemcpyDeviceToHost));
+    return GPIS_OK;
+}
+extern "C" int gpis_eval_value_host(gpis_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id)
+{
+    CHECK_ARGS(m && (n == 0 || (q && value)));
+    if (n == 0) return GPIS_OK;
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    int st;
+    if ((st = ensure_stage(m, 0, n * sizeof(gpis_query))) || (st = ensure_stage(m, 1, n * sizeof(float))) || (st = ensure_stage(m, 2, n * sizeof(int32_t))))
+        return st;
+    HIP_TRY(hipMemcpy(m->stage[0], q, n * sizeof(gpis_query), hipMemcpyHostToDevice));
+    st = gpis_eval_value_batch(m, n, (const gpis_query *)m->stage[0], (float *)m->stage[1], (int32_t *)m->stage[2], nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(value, m->stage[1], n * sizeof(float), hipMemcpyDeviceToHost));
+    if (gp_id) HIP_TRY(hipMemcpy(gp_id, m->stage[2], n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GPIS_OK;
+}
+extern "C" int gpis_eval_gradient_host(gpis_medium *m, size_t n, const gpis_query *q, float *grad3)
+{
+    CHECK_ARGS(m && (n == 0 || (q && grad3)));
+    if (n == 0) return GPIS_OK;
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    int st;
+    if ((st = ensure_stage(m, 0, n * sizeof(gpis_query))) || (st = ensure_stage(m, 1, 3 * n * sizeof(float))))
+        return st;
+    HIP_TRY(hipMemcpy(m->stage[0], q, n * sizeof(gpis_query), hipMemcpyHostToDevice));
+    st = gpis_eval_gradient_batch(m, n, (const gpis_query *)m->stage[0], (float *)m->stage[1], nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(grad3, m->stage[1], 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    return GPIS_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------
+extern "C" int gpis_get_counters(gpis_medium *m, uint64_t *n_eval, uint64_t *n_seg)
+{
+    CHECK_ARGS(m);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    Counters c;
+    HIP_TRY(hipMemcpy(&c, m->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    if (n_eval) *n_eval = c.n_eval;
+    if (n_seg) *n_seg = c.n_seg;
+    return GPIS_OK;
+}
+extern "C" int gpis_reset_counters(gpis_medium *m)
+{
+    CHECK_ARGS(m);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(m->d_counters, 0, sizeof(Counters)));
+    return GPIS_OK;
+}
+
+// ---- scene S driver ----------------------------------------------------------------------
+extern "C" void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp)
+{
+    memset(s, 0, sizeof *s);
+    s->width = width; s->height = height;
+    s->spp_begin = 0; s->spp_count = spp;
+    s->scene_seed = 0xBA5EBA11u;
+    s->tile_size = 16;
+    s->cam_pos[0] = 0.f; s->cam_pos[1] = 0.f; s->cam_pos[2] = 4.f;
+    s->cam_fov_deg = 35.f;
+    s->bound_radius = 1.5f;
+    s->light_dir[0] = 0.5f; s->light_dir[1] = 0.7f; s->light_dir[2] = 0.5f;
+    s->light_radiance = 1.f;
+    s->y_begin = 0; s->y_count = height;
+}
+
+extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum, uint32_t *hit_count, void *stream)
+{
+    CHECK_ARGS(m && s && radiance_sum);
+    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    SceneConst sc;
+    sc.s = *s;
+    const float pi_f = 3.1415926536f;
+    float fov_rad = s->cam_fov_deg * (pi_f / 180.0f);
+    sc.plane_dist = 1.0f / tanf(fov_rad * 0.5f);
+    sc.ratio = (float)s->height / (float)s->width;
+    sc.psx = 1.0f / (float)s->width;
+    {
+        float lx = s->light_dir[0], ly = s->light_dir[1], lz = s->light_dir[2];
+        float l2 = 0.f; l2 += lx * lx; l2 += ly * ly; l2 += lz * lz;
+        float inv = 1.0f / sqrtf(l2);
+        sc.light[0] = lx * inv; sc.light[1] = ly * inv; sc.light[2] = lz * inv;
+    }
+    const size_t total_pixels = (size_t)s->y_count * s->width;
+    const size_t first_pixel0 = (size_t)s->y_begin * s->width;
+    const size_t target_samples = (size_t)1 << 23;   // ~8 Mi samples (≈3 GB of workspace) per chunk
+    size_t chunk_pixels = target_samples / s->spp_count;
+    if (chunk_pixels < 1) chunk_pixels = 1;
+    if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
+    const size_t ns_max = chunk_pixels * s->spp_count;
+    // workspace: [prim rays | seg out | shadow rays | u_shadow | cosl | valid | valid2 | vis | hit]
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_prim = carve(ns_max * sizeof(gpis_ray_in)), o_seg = carve(ns_max * sizeof(gpis_seg_out)), o_sh = carve(ns_max * sizeof(gpis_ray_in));
+    size_t o_us = carve(ns_max * 4), o_cos = carve(ns_max * 4), o_v1 = carve(ns_max), o_v2 = carve(ns_max), o_vis = carve(ns_max), o_hit = carve(ns_max);
+    int rc = ensure_stage(m, 3, off);
+    if (rc) return rc;
+    char *ws = (char *)m->stage[3];
+    gpis_ray_in *prim = (gpis_ray_in *)(ws + o_prim);
+    gpis_seg_out *seg = (gpis_seg_out *)(ws + o_seg);
+    gpis_ray_in *sh = (gpis_ray_in *)(ws + o_sh);
+    float *us = (float *)(ws + o_us), *cosl = (float *)(ws + o_cos);
+    uint8_t *v1 = (uint8_t *)(ws + o_v1), *v2 = (uint8_t *)(ws + o_v2), *vis = (uint8_t *)(ws + o_vis), *hit = (uint8_t *)(ws + o_hit);
+    for (size_t p0 = 0; p0 < total_pixels; p0 += chunk_pixels) {
+        size_t np = total_pixels - p0 < chunk_pixels ? total_pixels - p0 : chunk_pixels;
+        size_t ns = np * s->spp_count;
+        k_scene_primary<<<grid_of(ns, 256), 256, 0, st>>>(sc, first_pixel0 + p0, ns, prim, us, v1);
+        if ((rc = launch_check("k_scene_primary"))) return rc;
+        if ((rc = sample_distance_impl(m, ns, prim, seg, nullptr, v1, st))) return rc;
+        k_scene_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, ns, prim, seg, us, v1, sh, cosl, v2, hit);
+        if ((rc = launch_check("k_scene_shade"))) return rc;
+        if ((rc = transmittance_impl(m, ns, sh, vis, v2, st))) return rc;
+        k_scene_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, first_pixel0 + p0, np, cosl, v2, vis, hit, radiance_sum, hit_count);
+        if ((rc = launch_check("k_scene_accumulate"))) return rc;
+    }
+    return GPIS_OK;
+}

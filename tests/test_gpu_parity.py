@@ -1,0 +1,385 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path behind the C ABI against the
+oracle on identical seeded inputs.
+
+Bars:  integer layer bit-exact; the 3D squared-exponential chain (the headline path) bit-exact
+in value, gradient, hit distance and hit/miss (the kernels use the reference's association order,
+no FMA contraction and a bit-exact expf); paths that call libm functions whose device version is
+not bit-identical (double exp/log/sin/cos in the non-stationary ramp, Box–Muller, NEE) within
+rtol 2e-5 / atol 2e-6 of fp32, with identical hit/miss except at a reported count of sign flips.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from gpu_util import to_dev, dev_empty, to_host, stream_ptr, scene_rays, shadow_rays_from
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-5, 2e-6
+
+
+@pytest.fixture(scope="module")
+def env(pkg, ob):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    lib = pkg.load_library()
+    return pkg, ob, lib
+
+
+def _queries(pkg, n, seed, spread=1.4, per_path=True):
+    rng = np.random.default_rng(seed)
+    q = np.zeros(n, dtype=pkg.QUERY)
+    q["p"] = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q["dir"] = d.astype(np.float32)
+    q["t_segment"] = rng.uniform(0, 2, n).astype(np.float32)
+    q["info_t"] = rng.uniform(0, 3, n).astype(np.float32)
+    if per_path:
+        q["pixel"] = rng.integers(0, 1920, (n, 2))
+        q["spp"] = rng.integers(0, 64, n)
+        q["segment"] = rng.integers(0, 4, n)
+    q["scene_seed"] = 0xBA5EBA11
+    # edge cases: cell faces (multiples of the cell size), negative cells, the origin
+    q["p"][0] = (0, 0, 0)
+    q["p"][1] = (-1.2, -0.3, -0.9)
+    q["p"][2] = (0.10606602, 0.21213204, -0.10606602)
+    q["dir"][3] = (0, 0, 1)
+    q["dir"][4] = (0, 0, -1)
+    q["dir"][5] = (1, 0, 0)
+    return q
+
+
+def test_integer_layer_bit_exact(env):
+    pkg, ob, lib = env
+    med = pkg.Medium(pkg.params_for_config("C0"))
+    rng = np.random.default_rng(5)
+    for arity in (1, 2, 3, 4):
+        words = rng.integers(0, 2 ** 32, size=(100000, arity), dtype=np.uint64).astype(np.uint32)
+        words[:3] = [[0] * arity, [0xFFFFFFFF] * arity, [0x80000000] * arity]
+        d_w, d_o = to_dev(words), dev_empty(4 * len(words))
+        med.call("gpis_xxhash32_batch", ctypes.c_size_t(len(words)), arity, d_w.data_ptr(), d_o.data_ptr(), stream_ptr())
+        assert np.array_equal(to_host(d_o, np.uint32), ob.xxhash32(words))
+    states = rng.integers(0, 2 ** 63, size=5000, dtype=np.uint64)
+    states[:3] = [0, 1, 0xFFFFFFFFFFFFFFFF]
+    d_s, d_o = to_dev(states), dev_empty(4 * 130 * len(states))
+    med.call("gpis_pcg32_stream_batch", ctypes.c_size_t(len(states)), d_s.data_ptr(), ctypes.c_uint32(130), d_o.data_ptr(), stream_ptr())
+    assert np.array_equal(to_host(d_o, np.uint32, (len(states), 130)), ob.pcg32_stream(states, 130))
+
+
+@pytest.mark.parametrize("cfg", ["C0", "C1"])
+def test_eval_value_gradient_bit_exact(env, cfg):
+    pkg, ob, lib = env
+    params = pkg.params_for_config(cfg)
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=8)
+    q = _queries(pkg, 4096, 11)
+    v_g, id_g = med.eval_value(q)
+    v_o, id_o = orc.eval_value(q)
+    g_g, g_o = med.eval_gradient(q), orc.eval_gradient(q)
+    assert np.array_equal(id_g, id_o)
+    bad_v = int((v_g.view(np.uint32) != v_o.view(np.uint32)).sum())
+    bad_g = int((g_g.view(np.uint32) != g_o.view(np.uint32)).sum())
+    assert bad_v == 0 and bad_g == 0, "bitwise mismatches: value %d, gradient %d of %d" % (bad_v, bad_g, len(q))
+    e_g, _ = med.counters()
+    assert e_g >= 2 * len(q)
+
+
+@pytest.mark.parametrize("cfg,res,step", [("C0", (256, 256), 5), ("C1", (480, 270), 7)])
+def test_march_bit_exact(env, cfg, res, step):
+    pkg, ob, lib = env
+    params = pkg.params_for_config(cfg)
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    scene = ob.default_scene_s(res[0], res[1], 2)
+    rays, us = scene_rays(ob, orc, scene, step=step)
+    assert len(rays) > 500
+    got, want = med.sample_distance(rays), orc.sample_distance(rays)
+    assert np.array_equal(got["ok"], want["ok"]) and np.array_equal(got["exited"], want["exited"])
+    assert np.array_equal(got["t"], want["t"])
+    for f in ("aniso", "sample_t", "continued_t", "weight", "continued_weight", "p", "last_val", "gp_id", "scheme"):
+        assert np.array_equal(got[f], want[f]), f
+    assert (want["exited"] == 0).sum() > 100 and (want["exited"] == 1).sum() > 100
+    sh = shadow_rays_from(ob, scene, rays, us, want)
+    assert len(sh) > 50
+    assert np.array_equal(med.transmittance(sh), orc.transmittance(sh))
+    # device-pointer entry gives the same bytes as the host-pointer convenience
+    d_r, d_o = to_dev(rays), dev_empty(rays.shape[0] * pkg.SEG_OUT.itemsize)
+    med.call("gpis_sample_distance_batch", ctypes.c_size_t(len(rays)), d_r.data_ptr(), d_o.data_ptr(), None, stream_ptr())
+    assert np.array_equal(to_host(d_o, pkg.SEG_OUT), got)
+
+
+def test_march_edge_cases(env):
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C1")
+    med, orc = pkg.Medium(params), ob.Oracle(params)
+    base = np.zeros((), dtype=pkg.RAY_IN)
+    base["pos"] = (0, 0, 4)
+    base["dir"] = (0, 0, -1)
+    base["near_t"], base["far_t"] = 2.5, 5.5
+    base["scene_seed"] = 0xBA5EBA11
+    base["first_scatter"] = 1
+    base["u_jitter"] = 0.37
+    rays = np.repeat(base[None], 8, axis=0).copy()
+    rays[1]["far_t"] = 0.0                       # maxT == 0 shortcut (GPM.cpp:239-248)
+    rays[1]["near_t"] = 0.0
+    rays[2]["far_t"] = np.inf                    # infinite far → near + 2000 (GPM.cpp:229-231); long march
+    rays[2]["pos"] = (0, 5, 4)                   # ... along a ray that stays outside: mean > 0 everywhere
+    rays[2]["near_t"] = 1990.0
+    rays[3]["bounce"] = 1024                     # bounce >= max_bounces → false (GPM.cpp:235)
+    rays[4]["near_t"], rays[4]["far_t"] = 2.5, 2.51   # shorter than one step: (far-near)/min_step
+    rays[5]["u_jitter"] = 0.0
+    rays[6]["u_jitter"] = np.float32(1) - np.float32(2 ** -24)
+    rays[7]["pos"] = (0, 0, 0.2)                 # starts inside the surface (negative field)
+    rays[7]["near_t"], rays[7]["far_t"] = 0.0, 1.0
+    got, want = med.sample_distance(rays), orc.sample_distance(rays)
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+    assert np.array_equal(med.transmittance(rays), orc.transmittance(rays))
+    # empty batch
+    assert med.sample_distance(rays[:0]).shape == (0,)
+
+
+@pytest.mark.parametrize("ctx", ["RENEWAL", "RENEWAL_PLUS", "NONE", "GLOBAL"])
+@pytest.mark.parametrize("iso", [0, 1])
+def test_per_path_realizations_and_conditioning(env, ctx, iso):
+    """single_realization=false: per-ray seeds, Renewal / Renewal+ conditioning live (SCN.cpp:21)."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C1")
+    params["single_realization"] = 0
+    params["isotropic_3d_sampling"] = iso
+    params["correlation_context"] = getattr(pkg.CTX, ctx)
+    params["impulse_density"] = 12
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    scene = ob.default_scene_s(192, 108, 1)
+    rays, us = scene_rays(ob, orc, scene, step=4)
+    got, want = med.sample_distance(rays, want_coeff=True), orc.sample_distance(rays, want_coeff=True)
+    assert np.array_equal(got[0]["exited"], want[0]["exited"]) and np.array_equal(got[0]["t"], want[0]["t"])
+    assert np.array_equal(got[0]["aniso"], want[0]["aniso"])
+    sh = shadow_rays_from(ob, scene, rays, us, want[0])
+    assert len(sh) > 20
+    g2, w2 = med.sample_distance(sh, want_coeff=True), orc.sample_distance(sh, want_coeff=True)
+    # conditioned second segments: same hit/miss, same distances, same coefficients
+    assert np.array_equal(g2[0]["exited"], w2[0]["exited"])
+    assert np.array_equal(g2[0]["t"], w2[0]["t"])
+    for f in ("value_scale", "gradient_scale", "ray_origin", "n_evals"):
+        assert np.array_equal(g2[1][f], w2[1][f]), f
+    assert np.array_equal(med.transmittance(sh), orc.transmittance(sh))
+    if ctx in ("RENEWAL", "RENEWAL_PLUS"):
+        assert np.abs(w2[1]["value_scale"]).max() > 0
+        # conditioning pins the value at the segment start to lastVal (= 0 on a surface)
+        q = np.zeros(len(sh), dtype=pkg.QUERY)
+        q["p"], q["dir"] = sh["pos"], sh["dir"]
+        for k in ("pixel", "spp", "segment", "scene_seed", "info_t"):
+            q[k] = sh[k]
+        q["coeff"] = w2[1]
+        v, _ = med.eval_value(q)
+        assert np.abs(v).max() < 2e-3
+        co = np.zeros(len(sh), dtype=pkg.COND_COEFF)
+        d_q, d_tv, d_tg, d_co = to_dev(q), to_dev(sh["last_val"]), to_dev(sh["last_aniso"].astype(np.float32)), dev_empty(co.nbytes)
+        med.call("gpis_conditioning_batch", ctypes.c_size_t(len(q)), d_q.data_ptr(), d_tv.data_ptr(), d_tg.data_ptr(), d_co.data_ptr(), stream_ptr())
+        co_g = to_host(d_co, pkg.COND_COEFF)
+        co_o = orc.conditioning(q, sh["last_val"], sh["last_aniso"].astype(np.float32))
+        for f in ("value_scale", "gradient_scale", "ray_origin", "n_evals"):
+            assert np.array_equal(co_g[f], co_o[f]), f
+
+
+def _close(a, b):
+    return np.allclose(a, b, rtol=RTOL, atol=ATOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("ctx,xy,scheme", [("RENEWAL_PLUS", 1, "MIS"), ("RENEWAL_PLUS", 0, "NEE"), ("RENEWAL", 0, "UNI"), ("NONE", 0, "MIS")])
+def test_1d_sampling_and_nee(env, ctx, xy, scheme):
+    """Config C2 family: 1D noise along the ray, xy gradient draws (Box–Muller in double → tolerance),
+    NEE pdf / gradient."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C2")
+    params["correlation_context"] = getattr(pkg.CTX, ctx)
+    params["correlation_xy"] = xy
+    params["scheme_1d"] = getattr(pkg.SCHEME, scheme)
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    q = _queries(pkg, 2048, 21)
+    v_g, _ = med.eval_value(q)
+    v_o, _ = orc.eval_value(q)
+    assert np.array_equal(v_g, v_o)             # the 1D value chain has no inexact libm call
+    assert _close(med.eval_gradient(q), orc.eval_gradient(q))
+    scene = ob.default_scene_s(160, 90, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    got, want = med.sample_distance(rays, want_coeff=True), orc.sample_distance(rays, want_coeff=True)
+    assert np.array_equal(got[0]["exited"], want[0]["exited"]) and np.array_equal(got[0]["t"], want[0]["t"])
+    assert _close(got[0]["aniso"], want[0]["aniso"])
+    assert np.array_equal(got[0]["scheme"], want[0]["scheme"])
+    sh = shadow_rays_from(ob, scene, rays, us, want[0])
+    g2, w2 = med.sample_distance(sh, want_coeff=True), orc.sample_distance(sh, want_coeff=True)
+    flips = int((g2[0]["exited"] != w2[0]["exited"]).sum())
+    assert flips <= max(1, len(sh) // 500), "hit/miss flips: %d of %d" % (flips, len(sh))
+    same = g2[0]["exited"] == w2[0]["exited"]
+    assert _close(g2[0]["t"][same], w2[0]["t"][same])
+    assert _close(g2[1]["value_scale"], w2[1]["value_scale"]) and _close(g2[1]["gradient_scale"], w2[1]["gradient_scale"])
+    # NEE
+    hit = (want[0]["exited"] == 0) & (want[0]["ok"] == 1)
+    n = int(hit.sum())
+    assert n > 50
+    nq = np.zeros(n, dtype=pkg.NEE_QUERY)
+    nq["ray_dir"], nq["p"] = rays["dir"][hit], want[0]["p"][hit]
+    nrm = want[0]["aniso"][hit]
+    nq["normal"] = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    nq["t_segment"] = want[0]["sample_t"][hit]
+    nq["info_t"] = want[0]["sample_t"][hit]
+    for k in ("pixel", "spp", "segment", "scene_seed"):
+        nq[k] = rays[k][hit]
+    nq["coeff"] = want[1][hit]
+    d_q, d_pdf, d_g = to_dev(nq), dev_empty(4 * n), dev_empty(12 * n)
+    med.call("gpis_nee_pdf_batch", ctypes.c_size_t(n), d_q.data_ptr(), d_pdf.data_ptr(), stream_ptr())
+    med.call("gpis_nee_grad_batch", ctypes.c_size_t(n), d_q.data_ptr(), d_g.data_ptr(), stream_ptr())
+    pdf_g, grad_g = to_host(d_pdf, np.float32), to_host(d_g, np.float32, (n, 3))
+    pdf_o, grad_o = orc.nee_pdf(nq), orc.nee_grad(nq)
+    assert np.allclose(grad_g, grad_o, rtol=1e-4, atol=1e-5)
+    assert np.allclose(pdf_g, pdf_o, rtol=2e-4, atol=1e-7)
+    assert np.isfinite(pdf_o).all() and (pdf_o >= 0).all()
+
+
+@pytest.mark.parametrize("iso,oned", [(1, 0), (0, 0), (1, 1)])
+def test_multi_resolution_nonstationary(env, iso, oned):
+    """Config C3 family: procedural length-scale ramp + two-level multi-resolution blend."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C3")
+    params["impulse_density"] = 16
+    params["isotropic_3d_sampling"] = iso
+    params["sampling_1d"] = oned
+    params["correlation_context"] = pkg.CTX.RENEWAL_PLUS
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    q = _queries(pkg, 1024, 31)
+    v_g, _ = med.eval_value(q)
+    v_o, _ = orc.eval_value(q)
+    assert _close(v_g, v_o)
+    assert np.allclose(med.eval_gradient(q), orc.eval_gradient(q), rtol=1e-4, atol=1e-4)
+    scene = ob.default_scene_s(128, 72, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    got, want = med.sample_distance(rays), orc.sample_distance(rays)
+    flips = int((got["exited"] != want["exited"]).sum())
+    assert flips <= max(1, len(rays) // 300), "hit/miss flips: %d of %d" % (flips, len(rays))
+    same = got["exited"] == want["exited"]
+    assert np.allclose(got["t"][same], want["t"][same], rtol=1e-4, atol=1e-4)
+
+
+def test_nonstationary_brute_force(env):
+    """proc_nonstationary without the multi-resolution grid (per-point kernel scale)."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C3")
+    params["impulse_density"] = 8
+    params["multi_resolution_grid"] = 0
+    params["isotropic_3d_sampling"] = 0
+    params["single_realization"] = 1
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    q = _queries(pkg, 512, 41, spread=1.2)
+    v_g, _ = med.eval_value(q)
+    v_o, _ = orc.eval_value(q)
+    assert np.allclose(v_g, v_o, rtol=1e-4, atol=1e-5)
+
+
+def test_aniso_and_linear_mean_and_csg(env):
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C0")
+    params["aniso"] = (1.0, 0.5, 2.0)
+    params["mean"]["type"] = pkg.MEAN_TYPE.LINEAR
+    params["mean"]["center"] = (0.0, -0.2, 0.0)
+    params["mean"]["dir"] = (0.2, 1.0, 0.1)
+    params["mean"]["scale"] = 0.8
+    params["mean"]["min"] = -0.5
+    params["has_mean_additional"] = 1
+    params["mean_additional"]["type"] = pkg.MEAN_TYPE.SPHERICAL
+    params["mean_additional"]["center"] = (0.3, 0.4, 0.0)
+    params["mean_additional"]["radius"] = 0.5
+    for iso in (0, 1):
+        params["isotropic_3d_sampling"] = iso
+        med, orc = pkg.Medium(params), ob.Oracle(params, threads=8)
+        q = _queries(pkg, 1024, 51)
+        v_g, i_g = med.eval_value(q)
+        v_o, i_o = orc.eval_value(q)
+        assert np.array_equal(i_g, i_o) and set(np.unique(i_o)) == {0, 1}
+        assert np.array_equal(v_g, v_o)
+        assert np.array_equal(med.eval_gradient(q), orc.eval_gradient(q))
+    hom = pkg.params_for_config("C0")
+    hom["mean"]["type"] = pkg.MEAN_TYPE.HOMOGENEOUS
+    hom["mean"]["offset"] = 0.05
+    med, orc = pkg.Medium(hom), ob.Oracle(hom)
+    q = _queries(pkg, 256, 52)
+    assert np.array_equal(med.eval_value(q)[0], orc.eval_value(q)[0])
+
+
+def test_use_aniso_mtx(env):
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C0")
+    params["use_aniso_mtx"] = 1
+    params["aniso_mtx"] = np.array([[1.0, 0.2, 0.0], [0.1, 0.8, 0.3], [0.0, -0.2, 1.5]], dtype=np.float32).ravel()
+    for iso in (0, 1):
+        params["isotropic_3d_sampling"] = iso
+        med, orc = pkg.Medium(params), ob.Oracle(params, threads=8)
+        q = _queries(pkg, 512, 61)
+        assert np.array_equal(med.eval_value(q)[0], orc.eval_value(q)[0])
+        assert np.array_equal(med.eval_gradient(q), orc.eval_gradient(q))
+        d_g, d_o = med.derived(), orc.derived()
+        assert np.array_equal(d_g["world_to_local"], d_o["world_to_local"])
+        assert d_g["kernel_radius_world"] == d_o["kernel_radius_world"]
+
+
+def test_derived_constants_match(env):
+    pkg, ob, lib = env
+    for cfg in ("C0", "C1", "C2"):
+        params = pkg.params_for_config(cfg)
+        d_g, d_o = pkg.Medium(params).derived(), ob.Oracle(params).derived()
+        for f in d_o.dtype.names:
+            if f == "fast_path":
+                continue
+            assert np.array_equal(d_g[f], d_o[f]), (cfg, f)
+
+
+def test_render_scene_s_small(env):
+    """Whole estimator (ray generation → sampleDistance → shading → shadow transmittance → per-pixel sum)."""
+    import torch
+    pkg, ob, lib = env
+    for cfg, (w, h, spp) in (("C0", (96, 96, 4)), ("C1", (96, 54, 8))):
+        params = pkg.params_for_config(cfg)
+        med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+        scene = ob.default_scene_s(w, h, spp)
+        want, hits_o = orc.render_scene_s(scene, want_hits=True)
+        rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+        hits = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+        sc = np.array(scene, dtype=pkg.SCENE_S)
+        med.reset_counters()
+        orc.reset_counters()
+        want2 = orc.render_scene_s(scene)
+        med.call("gpis_render_scene_s", sc.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), hits.data_ptr(), stream_ptr())
+        torch.cuda.synchronize()
+        got = rad.cpu().numpy().reshape(h, w)
+        assert np.array_equal(hits.cpu().numpy().reshape(h, w).astype(np.uint32), hits_o)
+        assert np.array_equal(got, want) and np.array_equal(want, want2)
+        assert want.max() > 0
+        assert med.counters() == orc.counters()
+        # row sharding (tile rows → ranks) reproduces the same image
+        rad2 = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+        for y0, yc in ((0, h // 3), (h // 3, h - h // 3)):
+            part = sc.copy()
+            part["y_begin"], part["y_count"] = y0, yc
+            med.call("gpis_render_scene_s", part.ctypes.data_as(ctypes.c_void_p), rad2.data_ptr(), None, stream_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(rad2.cpu().numpy().reshape(h, w), want)
+
+
+def test_error_behaviour(env):
+    pkg, ob, lib = env
+    bad = pkg.params_for_config("C0")
+    bad["correlation_context"] = 9          # the reference FAILs on an unknown context string (GPM.cpp:40)
+    with pytest.raises(RuntimeError, match="Invalid correlation context"):
+        pkg.Medium(bad)
+    bad = pkg.params_for_config("C0")
+    bad["scheme_1d"] = 7                    # SCNM.cpp:44
+    with pytest.raises(RuntimeError, match="sampling scheme"):
+        pkg.Medium(bad)
+    bad = pkg.params_for_config("C0")
+    bad["abi_version"] = 99
+    with pytest.raises(RuntimeError, match="abi_version"):
+        pkg.Medium(bad)
+    med = pkg.Medium(pkg.params_for_config("C0"))
+    st = med.L.lib.gpis_sample_distance_batch(med.h, 4, None, None, None, None)
+    assert st == -1 and "invalid argument" in med.L.last_error()
