@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — Msamples/s of the sparse-convolution GPIS hot path on scene S.
+
+A "step" renders one full frame of the configuration BASELINE.json quotes the metric on
+(C1: 1920x1080, 64 spp, 3D isotropic sampling, impulse_density=32, renewal, single realization):
+primary sampleDistance, shading, one shadow transmittance per hit, per-pixel accumulation.
+Inputs (the medium's constants, the workspace) are resident in HBM before the timed region.
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL): rank 0 broadcasts the parameter
+block; rank r renders sample indices [r*spp, (r+1)*spp) of every pixel (per-GPU work is fixed:
+weak scaling; every sample's randomness is a function of (pixel, spp index) only, so the sharded
+image equals the single-GPU image at spp*N); the per-rank radiance sums are reduced to rank 0
+inside the timed region (the one exchange step of the path).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md "Chip-level parameters")
+B_SEG = 224                    # bytes per segment: 128 in + 96 out
+
+
+def algorithmic_bytes_per_eval(params):
+    """27*rho*16*L bytes (3D) or 3*rho*8*L bytes (1D); L=2 for multi-resolution."""
+    rho = int(params["impulse_density"])
+    L = 2 if (params["nonstationary"] and params["multi_resolution_grid"]) else 1
+    return (3 * rho * 8 * L) if params["sampling_1d"] else (27 * rho * 16 * L)
+
+
+def load_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(kernel_key)
+    except Exception:
+        return None
+
+
+def cpu_baseline(pkg, params, cores):
+    """The oracle (CPU restatement, kind "port") on a bounded sample of the same workload: the
+    C1 scene with the same camera at 1/32 of the linear resolution (60x34 pixels, same spp)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_bindings as ob
+    orc = ob.Oracle(params, threads=cores)
+    w, h, spp = 60, 34, 64
+    scene = ob.default_scene_s(w, h, spp)
+    t0 = time.perf_counter()
+    orc.render_scene_s(scene)
+    dt = time.perf_counter() - t0
+    n_eval, n_seg = orc.counters()
+    return {
+        "value": w * h * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": "scene S, C1 medium, same camera at %dx%d, %d spp (%d samples, %.1f s, %d noise evals)" % (w, h, spp, w * h * spp, dt, n_eval),
+        "us_per_eval": dt * cores / max(n_eval, 1) * 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C1")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import _gpis_pkg
+    pkg = _gpis_pkg.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # rank 0 owns the scene/kernel parameters; broadcast the POD block over RCCL
+    params = pkg.params_for_config(args.config) if rank == 0 else np.zeros((), dtype=pkg.PARAMS)
+    if world > 1:
+        blob = torch.from_numpy(np.frombuffer(params.tobytes(), dtype=np.uint8).copy()).cuda()
+        dist.broadcast(blob, src=0)
+        params = np.frombuffer(blob.cpu().numpy().tobytes(), dtype=pkg.PARAMS)[0].copy()
+
+    med = pkg.Medium(params, device=local_rank)
+    lib = med.L.lib
+    W, H, spp = args.width, args.height, args.spp
+    scene = np.zeros((), dtype=pkg.SCENE_S)
+    lib.gpis_default_scene_s(scene.ctypes.data, W, H, spp)
+    scene["spp_begin"] = rank * spp          # weak scaling: each rank renders its own spp slice
+    rad = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        rad.zero_()
+        med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, stream)
+        if world > 1:
+            dist.reduce(rad, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    med.reset_counters()
+    med.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    med.set_profiling(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    prof = [med.kernel_profile(k) for k in (0, 1)]     # (ms, launches, n_eval, n_seg)
+    if rank == 0:
+        total_samples = W * H * spp * world * args.steps
+        b_eval = algorithmic_bytes_per_eval(params)
+        names = ("sample_distance", "transmittance")
+        dom = 0 if prof[0][0] >= prof[1][0] else 1
+        ms, launches, n_eval, n_seg = prof[dom]
+        bytes_alg = n_eval * b_eval + n_seg * B_SEG
+        achieved = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        fast = int(med.derived()["fast_path"])
+        kernel = ("k_fast_" if fast else "k_") + names[dom]
+        res = {
+            "metric": "Msamples/s (primary rays x spp / s)", "value": total_samples / dt_max / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: scene S %dx%d, %d spp/GPU, SparseConvolutionNoiseMedium (3D isotropic, "
+                                   "impulse_density=%d, ctx=renewal, single_realization)" % (args.config, W, H, spp, int(params["impulse_density"]))
+                       if args.config == "C1" else "%s: scene S %dx%d, %d spp/GPU" % (args.config, W, H, spp),
+                       "sharding": "spp-slice per rank + reduce(sum) to rank 0" if world > 1 else "single GPU",
+                       "kernel_path": "fast (cell table)" if fast else "generic (on-the-fly impulses)"},
+            "roofline": {
+                "bound": "hbm", "kernel": kernel,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": load_traffic(kernel),
+                "algorithmic_bytes_per_launch": bytes_alg / max(launches, 1),
+                "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                "bytes_per_eval": b_eval, "bytes_per_segment": B_SEG, "n_eval": n_eval, "n_seg": n_seg,
+                "evals_per_s": (prof[0][2] + prof[1][2]) / dt_max,
+                "kernel_ms": {names[0]: prof[0][0], names[1]: prof[1][0]},
+                "note": "impulses are generated or gathered on chip; the binding roof is VALU integer/fp32 issue, "
+                        "the HBM figure uses SURVEY.md 8d's algorithmic-bytes definition",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cores = os.cpu_count() or 1
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            res["cpu_baseline"] = cpu_baseline(pkg, params, cores)
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -296,6 +296,15 @@ int gpis_eval_gradient_host(gpis_medium *m, size_t n, const gpis_query *q, float
 int gpis_get_counters(gpis_medium *m, uint64_t *n_eval, uint64_t *n_seg);
 int gpis_reset_counters(gpis_medium *m);
 
+/* Per-kernel timing with HIP events recorded on the launch stream around every march-kernel
+ * launch (off by default; events cost a few microseconds per launch).  `which`: 0 = the
+ * sampleDistance kernel, 1 = the transmittance kernel.  Returns the summed kernel time, the
+ * number of launches, and that kernel's share of the evaluation / segment counters since the
+ * last gpis_reset_counters.  Synchronises the device. */
+int gpis_set_profiling(gpis_medium *m, int enable);
+int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_t *launches,
+                            uint64_t *n_eval, uint64_t *n_seg);
+
 /* ---- tile → ray-batch driver (SURVEY.md §8d "Scene S", §8f-1) -------------------- */
 
 typedef struct gpis_scene_s {

@@ -194,7 +194,8 @@ class GpisLib:
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
         "gpis_xxhash32_batch", "gpis_pcg32_stream_batch",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
-        "gpis_get_counters", "gpis_reset_counters", "gpis_default_scene_s", "gpis_render_scene_s",
+        "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
+        "gpis_default_scene_s", "gpis_render_scene_s",
     ]
 
     def __init__(self, path=None):
@@ -229,6 +230,8 @@ class GpisLib:
         L.gpis_eval_gradient_host.argtypes = [vp, sz, vp, vp]
         L.gpis_get_counters.argtypes = [vp, vp, vp]
         L.gpis_reset_counters.argtypes = [vp]
+        L.gpis_set_profiling.argtypes = [vp, i32]
+        L.gpis_get_kernel_profile.argtypes = [vp, i32, vp, vp, vp, vp]
         L.gpis_default_scene_s.argtypes = [vp, u32, u32, u32]
         L.gpis_default_scene_s.restype = None
         L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
@@ -323,6 +326,17 @@ class Medium:
 
     def reset_counters(self):
         self.L.check(self.L.lib.gpis_reset_counters(self.h), "gpis_reset_counters")
+
+    def set_profiling(self, on):
+        self.L.check(self.L.lib.gpis_set_profiling(self.h, int(bool(on))), "gpis_set_profiling")
+
+    def kernel_profile(self, which):
+        """(total_ms, launches, n_eval, n_seg) of the sampleDistance (0) / transmittance (1) kernel."""
+        ms = ctypes.c_double()
+        n, e, s = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self.L.check(self.L.lib.gpis_get_kernel_profile(self.h, int(which), ctypes.byref(ms), ctypes.byref(n),
+                                                        ctypes.byref(e), ctypes.byref(s)), "gpis_get_kernel_profile")
+        return ms.value, n.value, e.value, s.value
 
     # ---- device-pointer entries (raw addresses, e.g. torch tensors) ------------------
     def call(self, name, *args):

@@ -17,6 +17,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "gpis.h"
 #include "gpis_device.hpp"
@@ -69,6 +71,12 @@ struct gpis_medium {
     void *stage[4];
     size_t stage_bytes[4];
     std::mutex mu;
+    // optional per-kernel timing (gpis_set_profiling): event pairs around each march launch
+    bool profiling;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];
+    size_t events_used[2];
+    double prof_ms[2];
+    uint64_t prof_launches[2];
 };
 
 static int ensure_stage(gpis_medium *m, int slot, size_t bytes)
@@ -579,13 +587,15 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     m->device = device;
     for (int i = 0; i < 4; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
     m->d_model = nullptr; m->d_counters = nullptr;
+    m->profiling = false;
+    for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
     memset(&m->fast, 0, sizeof m->fast);
     int st = build_model(*params, m->host_model, m->derived);
     if (st != GPIS_OK) { delete m; return st; }
     hipError_t e = hipMalloc(&m->d_model, sizeof(DevModel));
-    if (e == hipSuccess) e = hipMalloc(&m->d_counters, sizeof(Counters));
+    if (e == hipSuccess) e = hipMalloc(&m->d_counters, 2 * sizeof(Counters));
     if (e == hipSuccess) e = hipMemcpy(m->d_model, &m->host_model, sizeof(DevModel), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(m->d_counters, 0, sizeof(Counters));
+    if (e == hipSuccess) e = hipMemset(m->d_counters, 0, 2 * sizeof(Counters));
     if (e != hipSuccess) {
         set_err(GPIS_ERR_DEVICE, "gpis_create: %s", hipGetErrorString(e));
         if (m->d_model) (void)hipFree(m->d_model);
@@ -611,6 +621,8 @@ extern "C" int gpis_destroy(gpis_medium *m)
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
     fast_table_free(&m->fast);
+    for (int k = 0; k < 2; ++k)
+        for (auto &ev : m->events[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int i = 0; i < 4; ++i)
         if (m->stage[i]) (void)hipFree(m->stage[i]);
     if (m->d_model) (void)hipFree(m->d_model);
@@ -639,10 +651,31 @@ static int launch_check(const char *what)
     return GPIS_OK;
 }
 
+struct ProfScope {   // records an event pair around one march-kernel launch when profiling is on
+    gpis_medium *m; int kind; hipStream_t s; bool on;
+    ProfScope(gpis_medium *m_, int kind_, hipStream_t s_) : m(m_), kind(kind_), s(s_), on(m_->profiling)
+    {
+        if (!on) return;
+        if (m->events_used[kind] == m->events[kind].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            m->events[kind].emplace_back(a, b);
+        }
+        (void)hipEventRecord(m->events[kind][m->events_used[kind]].first, s);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(m->events[kind][m->events_used[kind]].second, s);
+        m->events_used[kind]++;
+    }
+};
+
 static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff,
                                 const uint8_t *mask, hipStream_t s)
 {
     if (n == 0) return GPIS_OK;
+    ProfScope prof(m, 0, s);
     if (m->fast.cells && fast_supported(m->host_model)) {
         int st = fast_sample_distance(m->d_model, &m->fast, n, rays, out, coeff, mask, m->d_counters, s);
         if (st != GPIS_OK) return set_err(st, "fast sample_distance launch failed");
@@ -654,12 +687,13 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
 static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible, const uint8_t *mask, hipStream_t s)
 {
     if (n == 0) return GPIS_OK;
+    ProfScope prof(m, 1, s);
     if (m->fast.cells && fast_supported(m->host_model)) {
-        int st = fast_transmittance(m->d_model, &m->fast, n, rays, visible, mask, m->d_counters, s);
+        int st = fast_transmittance(m->d_model, &m->fast, n, rays, visible, mask, m->d_counters + 1, s);
         if (st != GPIS_OK) return set_err(st, "fast transmittance launch failed");
         return launch_check("k_fast_transmittance");
     }
-    k_transmittance<<<grid_of(n, kBlock), kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters);
+    k_transmittance<<<grid_of(n, kBlock), kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
     return launch_check("k_transmittance");
 }
 
@@ -809,10 +843,10 @@ extern "C" int gpis_get_counters(gpis_medium *m, uint64_t *n_eval, uint64_t *n_s
     CHECK_ARGS(m);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipDeviceSynchronize());
-    Counters c;
-    HIP_TRY(hipMemcpy(&c, m->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    if (n_eval) *n_eval = c.n_eval;
-    if (n_seg) *n_seg = c.n_seg;
+    Counters c[2];
+    HIP_TRY(hipMemcpy(c, m->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    if (n_eval) *n_eval = c[0].n_eval + c[1].n_eval;
+    if (n_seg) *n_seg = c[0].n_seg + c[1].n_seg;
     return GPIS_OK;
 }
 extern "C" int gpis_reset_counters(gpis_medium *m)
@@ -820,7 +854,35 @@ extern "C" int gpis_reset_counters(gpis_medium *m)
     CHECK_ARGS(m);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(m->d_counters, 0, sizeof(Counters)));
+    HIP_TRY(hipMemset(m->d_counters, 0, 2 * sizeof(Counters)));
+    for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
+    return GPIS_OK;
+}
+
+extern "C" int gpis_set_profiling(gpis_medium *m, int enable)
+{
+    CHECK_ARGS(m);
+    m->profiling = enable != 0;
+    return GPIS_OK;
+}
+extern "C" int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_t *launches, uint64_t *n_eval, uint64_t *n_seg)
+{
+    CHECK_ARGS(m && (which == 0 || which == 1));
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < m->events_used[which]; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, m->events[which][i].first, m->events[which][i].second));
+        m->prof_ms[which] += (double)ms;
+        m->prof_launches[which]++;
+    }
+    m->events_used[which] = 0;
+    Counters c[2];
+    HIP_TRY(hipMemcpy(c, m->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    if (total_ms) *total_ms = m->prof_ms[which];
+    if (launches) *launches = m->prof_launches[which];
+    if (n_eval) *n_eval = c[which].n_eval;
+    if (n_seg) *n_seg = c[which].n_seg;
     return GPIS_OK;
 }
 
