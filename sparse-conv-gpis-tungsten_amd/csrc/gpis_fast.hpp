@@ -1,20 +1,496 @@
-// gpis_fast.hpp — single-realization fast path (cell impulse table + wave-coherent cell sweep).
-// Placeholder until the kernels land: the table is never built, so the generic path runs.
+// gpis_fast.hpp — wave-cooperative fast path for single-realization media (configs C0, C1).
+//
+// With single_realization the seed of every cell is the same for every ray (SCN.cpp:40-42), so the
+// 64 rays of a wave that sit next to each other (consecutive spp of one pixel) need the SAME cells.
+// Instead of every lane regenerating 27 x rho impulses per evaluation, the wave
+//   1. reduces the lanes' grid positions to a bounding box (min/max over the wave),
+//   2. walks the union of the lanes' 3x3x3 neighbourhoods in lexicographic (x, y, z) order — which
+//      is every lane's own dx,dy,dz order (SCN.cpp:368-371), so each lane still accumulates its
+//      cells in the reference's order,
+//   3. generates each cell's impulse list ONCE, cooperatively: lane k jumps the cell's PCG32 stream
+//      ahead by 4k draws (LCG jump-ahead, state_k = A[k]*s0 + C[k] mod 2^64) and produces impulse k
+//      exactly as the sequential generator would (SCN.cpp:376-385); the list is staged in LDS,
+//   4. culls: lane k tests its impulse against the box of query points (sphere/box distance with
+//      slack), a ballot gives the wave-uniform candidate mask,
+//   5. consumes: for each candidate (scalar bit loop) every lane reads the impulse from LDS
+//      (broadcast read), applies the reference's unit-ball test and kernel in the reference's
+//      per-lane summation order (SCN.cpp:383-392).
+// A wave whose lanes are NOT close together (box wider than 2 cells on an axis) falls back to the
+// per-lane generator for that evaluation: results never depend on coherence, only speed does.
+//
+// The march (SCNM.cpp:102-183) runs as a per-lane phase machine driven in lockstep: every
+// iteration is one cooperative value evaluation for all lanes that still march / refine; the one
+// gradient evaluation each segment ends with (GPM.cpp:283, 319) is deferred until no lane marches
+// any more and done once for the whole wave.  During the march only the noise VALUE is summed (the
+// reference computes and discards the gradient there: SCN.cpp:76, SCN.hpp:62).
 #pragma once
 #include "gpis_device.hpp"
 
+#pragma clang fp contract(off)
+
 namespace gpis {
 
+// ---- LCG jump-ahead tables: state after n further draws = A_n * s + C_n -------------------
+struct JumpTable {
+    uint64_t A[64];
+    uint64_t C[64];
+};
+constexpr JumpTable make_jump_table()
+{
+    JumpTable t{};
+    uint64_t a = 1, c = 0;
+    for (int n = 0; n < 256; ++n) {
+        if ((n & 3) == 0) { t.A[n >> 2] = a; t.C[n >> 2] = c; }
+        a = a * kPcgMult;
+        c = c * kPcgMult + 1ULL;
+    }
+    return t;
+}
+__device__ const JumpTable kJump4 = make_jump_table();   // entry k: jump by 4k draws
+
 struct FastTable {
-    float4 *cells;   // nullptr → fast path unused
+    float4 *cells;   // reserved for an HBM-resident cell cache; nullptr = cells are generated per wave
+    int enabled;
 };
 
-inline bool fast_supported(const DevModel &) { return false; }
-inline int fast_table_build(const DevModel &, const DevModel *, FastTable *t) { t->cells = nullptr; return GPIS_OK; }
-inline void fast_table_free(FastTable *t) { t->cells = nullptr; }
-inline int fast_sample_distance(const DevModel *, const FastTable *, size_t, const gpis_ray_in *, gpis_seg_out *, gpis_cond_coeff *,
-                                const uint8_t *, Counters *, hipStream_t) { return GPIS_ERR_UNSUPPORTED; }
-inline int fast_transmittance(const DevModel *, const FastTable *, size_t, const gpis_ray_in *, uint8_t *, const uint8_t *, Counters *,
-                              hipStream_t) { return GPIS_ERR_UNSUPPORTED; }
+inline bool fast_supported(const DevModel &M)
+{
+    return M.single_realization && !M.sampling_1d && !M.nonstationary && !M.use_aniso_mtx && !M.absorption_only &&
+           M.n_impulses >= 1 && M.n_impulses <= 64;
+}
+inline int fast_table_build(const DevModel &M, const DevModel *, FastTable *t)
+{
+    t->cells = nullptr;
+    t->enabled = fast_supported(M) && !getenv("GPIS_DISABLE_FAST");
+    return GPIS_OK;
+}
+inline void fast_table_free(FastTable *t) { t->cells = nullptr; t->enabled = 0; }
+
+// ---- wave reductions (wave64) ----------------------------------------------------------------
+GPIS_DEV float wave_min_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+GPIS_DEV float wave_max_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+constexpr int kFastBlock = 64;          // one wave per workgroup
+struct FastLds {
+    float4 imp[64];                     // the current cell's impulses (x, y, z, w=+-1)
+};
+
+// One cooperative noise3D (SCN.cpp:362-395) for the lanes with `active` set.
+//   p      : the lane's query point in the space the grid lives in (world, or isotropic-ray space)
+//   R      : kernelRadius (wave-uniform);  A0..A2: diagonal of getInvCovMtx (wave-uniform)
+// Returns (value, gradient) — gradient only when GRAD.
+template <bool GRAD>
+GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    V3 pg = p / R;
+    V3 fl = v3(floorf(pg.x), floorf(pg.y), floorf(pg.z));
+    V3 frac = pg - fl;
+    int ci0 = (int)fl.x, cj0 = (int)fl.y, ck0 = (int)fl.z;
+
+    // bounding box of the active lanes' grid positions (inactive lanes contribute nothing)
+    const float big = 3.0e38f;
+    float bx0 = wave_min_f(active ? pg.x : big), bx1 = wave_max_f(active ? pg.x : -big);
+    float by0 = wave_min_f(active ? pg.y : big), by1 = wave_max_f(active ? pg.y : -big);
+    float bz0 = wave_min_f(active ? pg.z : big), bz1 = wave_max_f(active ? pg.z : -big);
+    if (!(bx0 <= bx1))
+        return v4(0.f, 0.f, 0.f, 0.f);   // no active lane in this wave
+    // cells are addressed with int coordinates; keep far away from overflow and from float→int UB
+    const float lim = 1.0e6f;
+    bool sane = bx0 > -lim && bx1 < lim && by0 > -lim && by1 < lim && bz0 > -lim && bz1 < lim;
+    int ilo = 0, ihi = 0, jlo = 0, jhi = 0, klo = 0, khi = 0;
+    if (sane) {
+        ilo = (int)floorf(bx0); ihi = (int)floorf(bx1);
+        jlo = (int)floorf(by0); jhi = (int)floorf(by1);
+        klo = (int)floorf(bz0); khi = (int)floorf(bz1);
+    }
+    const bool coherent = sane && (ihi - ilo) <= 1 && (jhi - jlo) <= 1 && (khi - klo) <= 1;
+    if (!coherent) {
+        // incoherent wave (or non-finite input): every lane generates its own impulses
+        V4 r = v4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+            float A[9] = {A0, 0.f, 0.f, 0.f, A1, 0.f, 0.f, 0.f, A2};
+            r = noise3d(M, p, seed, R, A, true);
+        }
+        return r;
+    }
+
+    const uint32_t n = M.n_impulses;
+    const uint64_t jA = kJump4.A[lane], jC = kJump4.C[lane];
+    V4 sum = v4(0.f, 0.f, 0.f, 0.f);
+    for (int ci = ilo - 1; ci <= ihi + 1; ++ci) {
+        const int di = ci - ci0;                              // per lane: this cell's dx
+        const float qx0 = bx0 - (float)ci, qx1 = bx1 - (float)ci;   // box of query points relative to the cell
+        for (int cj = jlo - 1; cj <= jhi + 1; ++cj) {
+            const int dj = cj - cj0;
+            const float qy0 = by0 - (float)cj, qy1 = by1 - (float)cj;
+            for (int ck = klo - 1; ck <= khi + 1; ++ck) {
+                const int dk = ck - ck0;
+                const bool mine = active && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
+                if (__ballot(mine) == 0ULL)
+                    continue;
+                const float qz0 = bz0 - (float)ck, qz1 = bz1 - (float)ck;
+                // --- generate impulse `lane` of this cell (SCN.cpp:376-385) ---
+                const uint32_t h = xxhash32_4((uint32_t)ck, (uint32_t)cj, (uint32_t)ci, seed) + 1u;
+                const uint64_t s0 = (uint64_t)h * (kPcgMult * kPcgMult) + (kPcgMult + 1ULL);   // set_state
+                Pcg32 g;
+                g.state = jA * s0 + jC;
+                float pz = normalized_uint(g.next_i());
+                float py = normalized_uint(g.next_i());
+                float px = normalized_uint(g.next_i());
+                float pw = (g.next_i() >> 31) ? 1.f : -1.f;
+                // sphere (radius 1) vs box-of-queries distance, with slack for the differently rounded test
+                float gx = fmaxf(fmaxf(qx0 - px, px - qx1), 0.f);
+                float gy = fmaxf(fmaxf(qy0 - py, py - qy1), 0.f);
+                float gz = fmaxf(fmaxf(qz0 - pz, pz - qz1), 0.f);
+                bool cand_k = (uint32_t)lane < n && (gx * gx + gy * gy + gz * gz) < 1.0001f;
+                unsigned long long cand = __ballot(cand_k);
+                if (cand == 0ULL)
+                    continue;
+                __builtin_amdgcn_wave_barrier();      // previous cell's reads are done before overwriting
+                lds.imp[lane] = make_float4(px, py, pz, pw);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // --- consume (SCN.cpp:383-392), candidates in ascending k = the reference's order ---
+                const V3 pc = frac - v3((float)di, (float)dj, (float)dk);
+                const V3 Rp = R * pc;
+                V4 cell = v4(0.f, 0.f, 0.f, 0.f);
+                while (cand) {
+                    const int k = __builtin_ctzll(cand);
+                    cand &= cand - 1ULL;
+                    const float4 im = lds.imp[k];
+                    if (mine) {
+                        V3 to_point = pc - v3(im.x, im.y, im.z);
+                        if (length_sq(to_point) < 1.0f) {
+                            V3 ab = Rp - R * v3(im.x, im.y, im.z);
+                            V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
+                            float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
+                            float f = expf_glibc(-absq);
+                            if (GRAD)
+                                cell = cell + im.w * v4(f, -2.f * t.x * f, -2.f * t.y * f, -2.f * t.z * f);
+                            else
+                                cell.v = cell.v + im.w * f;
+                        }
+                    }
+                }
+                if (mine) {
+                    if (GRAD) sum = sum + cell;
+                    else sum.v = sum.v + cell.v;
+                }
+            }
+        }
+    }
+    return sum;
+}
+
+// evaluateNoise3D for the stationary single-realization case (SCN.cpp:101-116, 251-260, 291-320):
+// per-lane transforms exactly as the generic path, the noise3D sum cooperatively.
+template <bool GRAD>
+GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, V3 rayDir, uint32_t &n_eval)
+{
+    if (active) n_eval++;
+    if (!M.iso3d) {
+        float R = M.radius_world;
+        // getInvCovMtx(isCov=false, isIsotropic=false, globalScale=1, localScale=1): ((A / 1) / 1) * 0.5
+        float A0 = M.invcov_world[0] / 1.f / 1.f * 0.5f, A1 = M.invcov_world[4] / 1.f / 1.f * 0.5f, A2 = M.invcov_world[8] / 1.f / 1.f * 0.5f;
+        V4 nz = coop_noise3d<GRAD>(M, lds, active, p, M.seed, R, A0, A1, A2);
+        return nz / M.norm3d_world;
+    }
+    V3 ray_dir_iso = normalized(cov_pos_w2l(M, rayDir, 1.0f));
+    Frame coord = frame_from_normal(ray_dir_iso);
+    V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
+    V4 nz = coop_noise3d<GRAD>(M, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f);
+    if (GRAD) {
+        V3 gw = cov_grad_l2w(M, to_global(coord, v3(nz.gx, nz.gy, nz.gz)), 1.0f);
+        return v4(nz.v, gw.x, gw.y, gw.z) / M.norm3d_iso;
+    }
+    return v4(nz.v / M.norm3d_iso, 0.f, 0.f, 0.f);
+}
+
+// evaluateValue, SCN.cpp:73-89
+GPIS_DEV float coop_evaluate_value(const DevModel &M, FastLds &lds, bool active, V3 p, V3 rayDir, int &gp_id, uint32_t &n_eval)
+{
+    float nv = coop_eval_noise3d<false>(M, lds, active, p, rayDir, n_eval).v;
+    double mean;
+    int id;
+    mean_weight_space(M, to_d(p), mean, id);
+    gp_id = id;
+    if (M.surf_vol_phase_separate)
+        gp_id = (1.f < M.surf_vol_phase_amp_thresh) ? 0 : 1;
+    return (float)((double)(M.sigma * nv) + mean);
+}
+// evaluateGradient, SCN.cpp:92-99
+GPIS_DEV V3 coop_evaluate_gradient(const DevModel &M, FastLds &lds, bool active, V3 p, V3 rayDir, uint32_t &n_eval)
+{
+    V4 nz = coop_eval_noise3d<true>(M, lds, active, p, rayDir, n_eval);
+    double mean;
+    int id;
+    mean_weight_space(M, to_d(p), mean, id);
+    V3 mg = to_f(mean_grad(M, id, to_d(p)));
+    return M.sigma * v3(nz.gx, nz.gy, nz.gz) + mg;
+}
+
+enum Phase : int { PH_INIT = 0, PH_MARCH = 1, PH_REFINE = 2, PH_FINAL = 3, PH_GRAD = 4, PH_DONE = 5 };
+
+// The march of one wave of segments.  WANT_SAMPLE: sampleDistance (GPM.cpp:221-341) — otherwise
+// transmittance (GPM.cpp:343-393), whose result does not depend on the end-of-segment gradient nor
+// on lastVal, so those two evaluations are not performed.
+template <bool WANT_SAMPLE>
+GPIS_DEV void fast_march(const DevModel &M, FastLds &lds, bool valid, const gpis_ray_in &ray, gpis_seg_out *out, bool &visible, uint32_t &n_eval)
+{
+    V3 pos = v3(ray.pos[0], ray.pos[1], ray.pos[2]), dir = v3(ray.dir[0], ray.dir[1], ray.dir[2]);
+    float nearT = ray.near_t, farT = ray.far_t;
+    if (!__builtin_isfinite(farT))
+        farT = (float)((double)nearT + 2000);
+    const float maxT = farT;
+    const bool first_scatter = ray.first_scatter != 0;
+    const V3d p0 = to_d(pos), rd = to_d(dir);
+    V3d rdn = rd;
+    { double inv = 1.0 / length_d(rd); rdn.x *= inv; rdn.y *= inv; rdn.z *= inv; }
+    float step_size = (farT - nearT) / (float)M.min_step;
+    if (M.step_size < step_size)
+        step_size = M.step_size;
+
+    int phase = PH_INIT;
+    bool early_ok = false;         // maxT == 0 shortcut
+    if (!valid)
+        phase = PH_DONE;
+    else if (WANT_SAMPLE && ray.bounce >= M.max_bounces)
+        phase = PH_DONE;
+    else if (WANT_SAMPLE && maxT == 0.f) {
+        phase = PH_DONE;
+        early_ok = true;
+    }
+    double t = (double)nearT, pf = 0., a_lo = 0., intp = 0., t_test = 0., t_prev = 0.;
+    int sign0 = 1, step = 0, gp = ray.last_gp_id;
+    float last_val = ray.last_val;
+    bool hit = false;
+    double t_query = (double)nearT;
+
+    for (;;) {
+        const bool want_val = phase <= PH_FINAL;
+        if (__ballot(want_val) == 0ULL)
+            break;
+        int gp_new;
+        float fv = coop_evaluate_value(M, lds, want_val, to_f(ray_at(p0, rd, t_query)), dir, gp_new, n_eval);
+        if (!want_val)
+            continue;
+        gp = gp_new;
+        const double f = (double)fv;
+        if (phase == PH_INIT) {
+            sign0 = f < 0 ? -1 : 1;
+            pf = f;
+            t = (double)(nearT + step_size * ray.u_jitter);
+            phase = (t < (double)farT) ? PH_MARCH : PH_FINAL;
+            t_query = phase == PH_MARCH ? t : (double)farT;
+        } else if (phase == PH_MARCH) {
+            step++;
+            const int signc = f < 0 ? -1 : 1;
+            if (!first_scatter && step == 1) {
+                sign0 = signc;
+                pf = f;
+                t += (double)step_size;
+            } else if (signc != sign0) {
+                intp = pf / (pf - f);
+                a_lo = t - (double)step_size;
+                t_prev = lerp_d(a_lo, t, intp);
+                t_test = t_prev;
+                phase = PH_REFINE;
+            } else {
+                pf = f;
+                t += (double)step_size;
+            }
+            if (phase == PH_MARCH) {
+                if (t < (double)farT) {
+                    t_query = t;
+                } else {
+                    phase = PH_FINAL;
+                    t_query = (double)farT;
+                }
+            } else {
+                t_query = t_test;
+            }
+        } else if (phase == PH_REFINE) {
+            const int sign_test = f < 0 ? -1 : 1;
+            bool done = false;
+            if (sign_test == sign0) {
+                done = true;
+            } else {
+                intp *= 0.9;
+                if (intp <= 0.01) {
+                    t_prev = t_test = 0;
+                    done = true;
+                } else {
+                    t_prev = t_test;
+                    t_test = lerp_d(a_lo, t, intp);
+                    t_query = t_test;
+                }
+            }
+            if (done) {
+                t = t_prev;
+                hit = true;
+                last_val = 0.0f;
+                phase = WANT_SAMPLE ? PH_GRAD : PH_DONE;
+            }
+        } else {   // PH_FINAL: the lastVal evaluation at farT (SCNM.cpp:181)
+            t = (double)farT;
+            last_val = fv;
+            hit = false;
+            phase = WANT_SAMPLE ? PH_GRAD : PH_DONE;
+        }
+        if (!WANT_SAMPLE && phase == PH_FINAL) {
+            // transmittance: the segment exits; lastVal is not part of the result
+            t = (double)farT;
+            hit = false;
+            phase = PH_DONE;
+        }
+    }
+    visible = valid && !hit;
+    if (!WANT_SAMPLE)
+        return;
+
+    // one gradient evaluation per segment (GPM.cpp:283 on a hit, GPM.cpp:319 on exit)
+    const bool want_grad = phase == PH_GRAD;
+    V3 g = v3(0.f, 0.f, 0.f);
+    if (__ballot(want_grad) != 0ULL)
+        g = coop_evaluate_gradient(M, lds, want_grad, to_f(ray_at(p0, rdn, t)), dir, n_eval);
+    if (!valid)
+        return;
+
+    gpis_seg_out o;
+    o.t = 0.;
+    o.sample_t = 0.f; o.continued_t = 0.f;
+    for (int c = 0; c < 3; ++c) { o.weight[c] = 0.f; o.continued_weight[c] = 0.f; o.p[c] = 0.f; }
+    o.exited = 0; o.ok = 0; o.scheme = GPIS_UNI;
+    o.gp_id = ray.last_gp_id;
+    o.last_val = ray.last_val;
+    o.aniso[0] = ray.last_aniso[0]; o.aniso[1] = ray.last_aniso[1]; o.aniso[2] = ray.last_aniso[2];
+    if (early_ok) {
+        o.weight[0] = o.weight[1] = o.weight[2] = 1.f;
+        o.exited = 1;
+        V3 pp = pos + dir * o.sample_t;
+        o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
+        o.ok = 1;
+        *out = o;
+        return;
+    }
+    if (!want_grad) {   // bounce limit
+        *out = o;
+        return;
+    }
+    V3d aniso = to_d(g);
+    o.t = t;
+    o.exited = hit ? 0 : 1;
+    o.last_val = last_val;
+    o.gp_id = gp;
+    bool ok = true;
+    if (hit) {
+        double avg = (aniso.x + aniso.y + aniso.z) / 3.0;
+        if (!__builtin_isfinite(avg)) {
+            aniso = V3d{1., 0., 0.};
+            ok = false;
+        } else {
+            double d = aniso.x * (double)dir.x; d += aniso.y * (double)dir.y; d += aniso.z * (double)dir.z;
+            double l2 = 0.; l2 += aniso.x * aniso.x; l2 += aniso.y * aniso.y; l2 += aniso.z * aniso.z;
+            if (d > 0) {
+                ok = false;
+            } else if (l2 < (double)0.0000001f) {
+                aniso = V3d{1., 0., 0.};
+                ok = false;
+            }
+        }
+    }
+    o.aniso[0] = aniso.x; o.aniso[1] = aniso.y; o.aniso[2] = aniso.z;
+    if (ok) {
+        float ft = (float)t;
+        o.sample_t = ft < maxT ? ft : maxT;
+        o.continued_t = ft;
+        for (int c = 0; c < 3; ++c) {
+            o.weight[c] = 1.f * M.sigma_s_over_t[c];
+            o.continued_weight[c] = 1.f * M.sigma_s_over_t[c];
+        }
+        V3 pp = pos + dir * o.sample_t;
+        o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
+        o.ok = 1;
+    }
+    *out = o;
+}
+
+__device__ __forceinline__ void fast_flush_counters(Counters *cnt, uint32_t n_eval, uint32_t n_seg)
+{
+    unsigned long long e = n_eval, s = n_seg;
+    for (int off = 32; off > 0; off >>= 1) {
+        e += __shfl_down(e, off, 64);
+        s += __shfl_down(s, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (e) atomicAdd(&cnt->n_eval, e);
+        if (s) atomicAdd(&cnt->n_seg, s);
+    }
+}
+
+__global__ void __launch_bounds__(kFastBlock) k_fast_sample_distance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+                                                                    gpis_seg_out *__restrict__ out, gpis_cond_coeff *__restrict__ coeff,
+                                                                    const uint8_t *__restrict__ mask, Counters *cnt)
+{
+    __shared__ FastLds lds;
+    size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
+    const bool valid = i < n && (!mask || mask[i]);
+    gpis_ray_in ray;
+    if (valid) ray = rays[i];
+    else memset(&ray, 0, sizeof ray);
+    uint32_t n_eval = 0;
+    bool vis;
+    gpis_seg_out *o = valid ? &out[i] : nullptr;
+    gpis_seg_out tmp;
+    fast_march<true>(*Mp, lds, valid, ray, valid ? o : &tmp, vis, n_eval);
+    if (valid && coeff) {
+        gpis_cond_coeff c;
+        memset(&c, 0, sizeof c);
+        c.n_evals = n_eval;
+        coeff[i] = c;
+    }
+    fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
+}
+
+__global__ void __launch_bounds__(kFastBlock) k_fast_transmittance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+                                                                  uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
+{
+    __shared__ FastLds lds;
+    size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
+    const bool valid = i < n && (!mask || mask[i]);
+    gpis_ray_in ray;
+    if (valid) ray = rays[i];
+    else memset(&ray, 0, sizeof ray);
+    uint32_t n_eval = 0;
+    bool vis = false;
+    fast_march<false>(*Mp, lds, valid, ray, nullptr, vis, n_eval);
+    if (i < n)
+        visible[i] = (valid && vis) ? 1 : 0;
+    fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
+}
+
+inline int fast_sample_distance(const DevModel *d_model, const FastTable *, size_t n, const gpis_ray_in *rays, gpis_seg_out *out,
+                                gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, hipStream_t s)
+{
+    unsigned grid = (unsigned)((n + kFastBlock - 1) / kFastBlock);
+    k_fast_sample_distance<<<grid, kFastBlock, 0, s>>>(d_model, n, rays, out, coeff, mask, cnt);
+    return GPIS_OK;
+}
+inline int fast_transmittance(const DevModel *d_model, const FastTable *, size_t n, const gpis_ray_in *rays, uint8_t *visible,
+                              const uint8_t *mask, Counters *cnt, hipStream_t s)
+{
+    unsigned grid = (unsigned)((n + kFastBlock - 1) / kFastBlock);
+    k_fast_transmittance<<<grid, kFastBlock, 0, s>>>(d_model, n, rays, visible, mask, cnt);
+    return GPIS_OK;
+}
 
 }   // namespace gpis

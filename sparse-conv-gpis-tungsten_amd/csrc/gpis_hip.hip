@@ -66,7 +66,7 @@ struct gpis_medium {
     int device;
     DevModel *d_model;
     Counters *d_counters;
-    FastTable fast;          // single-realization cell table (gpis_fast.hpp); cells == nullptr when unused
+    FastTable fast;          // single-realization wave-cooperative path (gpis_fast.hpp); enabled == 0 when unused
     // staging for the *_host entries and workspace for the renderer (grown on demand)
     void *stage[4];
     size_t stage_bytes[4];
@@ -610,7 +610,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         delete m;
         return st;
     }
-    m->derived.fast_path = m->fast.cells != nullptr;
+    m->derived.fast_path = m->fast.enabled;
     *out = m;
     return GPIS_OK;
 }
@@ -676,7 +676,7 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
 {
     if (n == 0) return GPIS_OK;
     ProfScope prof(m, 0, s);
-    if (m->fast.cells && fast_supported(m->host_model)) {
+    if (m->fast.enabled) {
         int st = fast_sample_distance(m->d_model, &m->fast, n, rays, out, coeff, mask, m->d_counters, s);
         if (st != GPIS_OK) return set_err(st, "fast sample_distance launch failed");
         return launch_check("k_fast_sample_distance");
@@ -688,7 +688,7 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
 {
     if (n == 0) return GPIS_OK;
     ProfScope prof(m, 1, s);
-    if (m->fast.cells && fast_supported(m->host_model)) {
+    if (m->fast.enabled) {
         int st = fast_transmittance(m->d_model, &m->fast, n, rays, visible, mask, m->d_counters + 1, s);
         if (st != GPIS_OK) return set_err(st, "fast transmittance launch failed");
         return launch_check("k_fast_transmittance");

@@ -86,11 +86,27 @@ def test_eval_value_gradient_bit_exact(env, cfg):
     assert e_g >= 2 * len(q)
 
 
+def _medium(pkg, params, path):
+    """path 'fast': the wave-cooperative single-realization kernels; 'generic': lane-per-ray kernels."""
+    import os
+    if path == "generic":
+        os.environ["GPIS_DISABLE_FAST"] = "1"
+    else:
+        os.environ.pop("GPIS_DISABLE_FAST", None)
+    try:
+        med = pkg.Medium(params)
+    finally:
+        os.environ.pop("GPIS_DISABLE_FAST", None)
+    assert int(med.derived()["fast_path"]) == (1 if path == "fast" else 0)
+    return med
+
+
+@pytest.mark.parametrize("path", ["fast", "generic"])
 @pytest.mark.parametrize("cfg,res,step", [("C0", (256, 256), 5), ("C1", (480, 270), 7)])
-def test_march_bit_exact(env, cfg, res, step):
+def test_march_bit_exact(env, cfg, res, step, path):
     pkg, ob, lib = env
     params = pkg.params_for_config(cfg)
-    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    med, orc = _medium(pkg, params, path), ob.Oracle(params, threads=16)
     scene = ob.default_scene_s(res[0], res[1], 2)
     rays, us = scene_rays(ob, orc, scene, step=step)
     assert len(rays) > 500
@@ -109,10 +125,11 @@ def test_march_bit_exact(env, cfg, res, step):
     assert np.array_equal(to_host(d_o, pkg.SEG_OUT), got)
 
 
-def test_march_edge_cases(env):
+@pytest.mark.parametrize("path", ["fast", "generic"])
+def test_march_edge_cases(env, path):
     pkg, ob, lib = env
     params = pkg.params_for_config("C1")
-    med, orc = pkg.Medium(params), ob.Oracle(params)
+    med, orc = _medium(pkg, params, path), ob.Oracle(params)
     base = np.zeros((), dtype=pkg.RAY_IN)
     base["pos"] = (0, 0, 4)
     base["dir"] = (0, 0, -1)
@@ -344,13 +361,49 @@ def test_derived_constants_match(env):
             assert np.array_equal(d_g[f], d_o[f]), (cfg, f)
 
 
-def test_render_scene_s_small(env):
+@pytest.mark.parametrize("path", ["fast", "generic"])
+def test_incoherent_and_ragged_waves(env, path):
+    """Rays in random order / random directions (waves whose lanes share no cells), batches that are
+    not a multiple of 64, and neighbouring lanes straddling cell boundaries."""
+    pkg, ob, lib = env
+    rng = np.random.default_rng(77)
+    for cfg in ("C0", "C1"):
+        params = pkg.params_for_config(cfg)
+        med, orc = _medium(pkg, params, path), ob.Oracle(params, threads=16)
+        n = 64 * 5 + 37
+        rays = np.zeros(n, dtype=pkg.RAY_IN)
+        o = rng.standard_normal((n, 3))
+        o = 1.5 * o / np.linalg.norm(o, axis=1, keepdims=True)
+        tgt = rng.uniform(-0.9, 0.9, (n, 3))
+        d = tgt - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays["pos"], rays["dir"] = o.astype(np.float32), d.astype(np.float32)
+        rays["near_t"] = 0.0
+        rays["far_t"] = rng.uniform(0.4, 1.6, n).astype(np.float32)
+        rays["u_jitter"] = rng.uniform(0, 1, n).astype(np.float32)
+        rays["first_scatter"] = rng.integers(0, 2, n)
+        rays["scene_seed"] = 0xBA5EBA11
+        rays["pixel"] = rng.integers(0, 500, (n, 2))
+        # a coherent bundle marching along a cell face: lanes straddle the boundary
+        R = float(orc.derived()["kernel_radius_world"])
+        rays["pos"][:64] = (R * 3 + 1e-6 * np.arange(64)[:, None] * np.array([1, -1, 1])).astype(np.float32) * np.array([1, 1, 0]) + np.array([0, 0, 1.4])
+        rays["dir"][:64] = (0, 0, -1)
+        rays["far_t"][:64] = 1.2
+        got, want = med.sample_distance(rays), orc.sample_distance(rays)
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], want[f], equal_nan=True), (cfg, f)
+        assert np.array_equal(med.transmittance(rays), orc.transmittance(rays))
+        assert 0 < (want["exited"] == 0).sum() < n
+
+
+@pytest.mark.parametrize("path", ["fast", "generic"])
+def test_render_scene_s_small(env, path):
     """Whole estimator (ray generation → sampleDistance → shading → shadow transmittance → per-pixel sum)."""
     import torch
     pkg, ob, lib = env
     for cfg, (w, h, spp) in (("C0", (96, 96, 4)), ("C1", (96, 54, 8))):
         params = pkg.params_for_config(cfg)
-        med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+        med, orc = _medium(pkg, params, path), ob.Oracle(params, threads=16)
         scene = ob.default_scene_s(w, h, spp)
         want, hits_o = orc.render_scene_s(scene, want_hits=True)
         rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
@@ -365,7 +418,15 @@ def test_render_scene_s_small(env):
         assert np.array_equal(hits.cpu().numpy().reshape(h, w).astype(np.uint32), hits_o)
         assert np.array_equal(got, want) and np.array_equal(want, want2)
         assert want.max() > 0
-        assert med.counters() == orc.counters()
+        e_g, s_g = med.counters()
+        e_o, s_o = orc.counters()
+        assert s_g == s_o
+        if path == "generic":
+            assert e_g == e_o
+        else:
+            # the cooperative transmittance kernel skips the one end-of-segment evaluation whose
+            # result cannot reach the output (gradient on a hit, lastVal on exit: GPM.cpp:371-392)
+            assert e_g == e_o - med.kernel_profile(1)[3]
         # row sharding (tile rows → ranks) reproduces the same image
         rad2 = torch.zeros(h * w, dtype=torch.float32, device="cuda")
         for y0, yc in ((0, h // 3), (h // 3, h - h // 3)):
