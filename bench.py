@@ -48,6 +48,22 @@ def load_traffic(kernel_key):
         return None
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but grants a 16-CPU share per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(pkg, params, cores):
     """The oracle (CPU restatement, kind "port") on a bounded sample of the same workload: the
     C1 scene with the same camera at 1/32 of the linear resolution (60x34 pixels, same spp)."""
@@ -160,7 +176,7 @@ def main():
                                    "impulse_density=%d, ctx=renewal, single_realization)" % (args.config, W, H, spp, int(params["impulse_density"]))
                        if args.config == "C1" else "%s: scene S %dx%d, %d spp/GPU" % (args.config, W, H, spp),
                        "sharding": "spp-slice per rank + reduce(sum) to rank 0" if world > 1 else "single GPU",
-                       "kernel_path": "fast (cell table)" if fast else "generic (on-the-fly impulses)"},
+                       "kernel_path": "fast (wave-cooperative cells in LDS)" if fast else "generic (on-the-fly impulses)"},
             "roofline": {
                 "bound": "hbm", "kernel": kernel,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -175,11 +191,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            cores = os.cpu_count() or 1
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
+            cores = usable_cores()
             res["cpu_baseline"] = cpu_baseline(pkg, params, cores)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
