@@ -381,9 +381,10 @@ GPIS_DEV float cov_xf_scale(const DevModel &M, float globalScale)
         return globalScale;
     return M.multi_resolution_grid ? globalScale : M.ls_maxval;
 }
-GPIS_DEV V3 cov_pos_w2l(const DevModel &M, V3 v, float s) { return eig_matvec(M.w2l, v) / cov_xf_scale(M, s); }
-GPIS_DEV V3 cov_grad_w2l(const DevModel &M, V3 v, float s) { return eig_matvec(M.l2w_T, v) * cov_xf_scale(M, s); }
-GPIS_DEV V3 cov_grad_l2w(const DevModel &M, V3 v, float s) { return eig_matvec(M.w2l_T, v) / cov_xf_scale(M, s); }
+// x / 1.0f and x * 1.0f are exact, so the (wave-uniform) unit scale of stationary kernels skips the IEEE divide
+GPIS_DEV V3 cov_pos_w2l(const DevModel &M, V3 v, float s) { float c = cov_xf_scale(M, s); V3 r = eig_matvec(M.w2l, v); return c == 1.0f ? r : r / c; }
+GPIS_DEV V3 cov_grad_w2l(const DevModel &M, V3 v, float s) { float c = cov_xf_scale(M, s); V3 r = eig_matvec(M.l2w_T, v); return c == 1.0f ? r : r * c; }
+GPIS_DEV V3 cov_grad_l2w(const DevModel &M, V3 v, float s) { float c = cov_xf_scale(M, s); V3 r = eig_matvec(M.w2l_T, v); return c == 1.0f ? r : r / c; }
 GPIS_DEV float cov_splat_cov_1d(const DevModel &M, V3 pq, V3 pc)
 {
     if (!M.nonstationary)

@@ -9,12 +9,13 @@
 //      cells in the reference's order,
 //   3. generates each cell's impulse list ONCE, cooperatively: lane k jumps the cell's PCG32 stream
 //      ahead by 4k draws (LCG jump-ahead, state_k = A[k]*s0 + C[k] mod 2^64) and produces impulse k
-//      exactly as the sequential generator would (SCN.cpp:376-385); the list is staged in LDS,
+//      exactly as the sequential generator would (SCN.cpp:376-385); impulse k stays in lane k's
+//      registers,
 //   4. culls: lane k tests its impulse against the box of query points (sphere/box distance with
 //      slack), a ballot gives the wave-uniform candidate mask,
-//   5. consumes: for each candidate (scalar bit loop) every lane reads the impulse from LDS
-//      (broadcast read), applies the reference's unit-ball test and kernel in the reference's
-//      per-lane summation order (SCN.cpp:383-392).
+//   5. consumes: for each candidate (scalar bit loop) the impulse is broadcast with v_readlane and
+//      every lane applies the reference's unit-ball test and kernel in the reference's per-lane
+//      summation order (SCN.cpp:383-392).
 // A wave whose lanes are NOT close together (box wider than 2 cells on an axis) falls back to the
 // per-lane generator for that evaluation: results never depend on coherence, only speed does.
 //
@@ -80,8 +81,54 @@ GPIS_DEV float wave_max_f(float v)
 
 constexpr int kFastBlock = 64;          // one wave per workgroup
 struct FastLds {
-    float4 imp[64];                     // the current cell's impulses (x, y, z, w=+-1)
+    uint64_t exptab[32];                // glibc's exp2f table, staged once per wave (ds_read_b64 per use)
 };
+GPIS_DEV void fast_lds_init(FastLds &lds)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    if (lane < 32)
+        lds.exptab[lane] = kExp2fTab[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// wave-uniform value → SGPR
+GPIS_DEV int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+GPIS_DEV float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// lane k's value, k wave-uniform (v_readlane_b32: no LDS round trip)
+GPIS_DEV float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
+// expf_glibc with the table in LDS and the range checks folded into selects (same results)
+GPIS_DEV float expf_glibc_lds(const FastLds &lds, float x)
+{
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32;
+    const double Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    double z = InvLn2N * (double)x;
+    double kd = z + Shift;
+    uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    uint64_t t = lds.exptab[ki & 31];
+    kd -= Shift;
+    double r = z - kd;
+    t += ki << (52 - 5);
+    double zz = __builtin_fma(C0, r, C1);
+    double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(zz, r2, y);
+    y = y * __longlong_as_double((long long)t);
+    float res = (float)y;
+    res = x < -0x1.9fe368p6f ? 0.0f : res;
+    res = x > 0x1.62e42ep6f ? __builtin_huge_valf() : res;
+    return res;
+}
+
+// cold path: every lane generates its own impulses
+GPIS_DEV V4 noise3d_per_lane(const DevModel &M, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
+{
+    float A[9] = {A0, 0.f, 0.f, 0.f, A1, 0.f, 0.f, 0.f, A2};
+    return noise3d(M, p, seed, R, A, true);
+}
 
 // One cooperative noise3D (SCN.cpp:362-395) for the lanes with `active` set.
 //   p      : the lane's query point in the space the grid lives in (world, or isotropic-ray space)
@@ -98,9 +145,9 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uin
 
     // bounding box of the active lanes' grid positions (inactive lanes contribute nothing)
     const float big = 3.0e38f;
-    float bx0 = wave_min_f(active ? pg.x : big), bx1 = wave_max_f(active ? pg.x : -big);
-    float by0 = wave_min_f(active ? pg.y : big), by1 = wave_max_f(active ? pg.y : -big);
-    float bz0 = wave_min_f(active ? pg.z : big), bz1 = wave_max_f(active ? pg.z : -big);
+    const float bx0 = uni_f(wave_min_f(active ? pg.x : big)), bx1 = uni_f(wave_max_f(active ? pg.x : -big));
+    const float by0 = uni_f(wave_min_f(active ? pg.y : big)), by1 = uni_f(wave_max_f(active ? pg.y : -big));
+    const float bz0 = uni_f(wave_min_f(active ? pg.z : big)), bz1 = uni_f(wave_max_f(active ? pg.z : -big));
     if (!(bx0 <= bx1))
         return v4(0.f, 0.f, 0.f, 0.f);   // no active lane in this wave
     // cells are addressed with int coordinates; keep far away from overflow and from float→int UB
@@ -116,10 +163,8 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uin
     if (!coherent) {
         // incoherent wave (or non-finite input): every lane generates its own impulses
         V4 r = v4(0.f, 0.f, 0.f, 0.f);
-        if (active) {
-            float A[9] = {A0, 0.f, 0.f, 0.f, A1, 0.f, 0.f, 0.f, A2};
-            r = noise3d(M, p, seed, R, A, true);
-        }
+        if (active)
+            r = noise3d_per_lane(M, p, seed, R, A0, A1, A2);
         return r;
     }
 
@@ -155,30 +200,26 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uin
                 unsigned long long cand = __ballot(cand_k);
                 if (cand == 0ULL)
                     continue;
-                __builtin_amdgcn_wave_barrier();      // previous cell's reads are done before overwriting
-                lds.imp[lane] = make_float4(px, py, pz, pw);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // --- consume (SCN.cpp:383-392), candidates in ascending k = the reference's order ---
+                // --- consume (SCN.cpp:383-392), candidates in ascending k = the reference's order;
+                //     impulse k lives in lane k's registers and is broadcast with v_readlane ---
                 const V3 pc = frac - v3((float)di, (float)dj, (float)dk);
                 const V3 Rp = R * pc;
                 V4 cell = v4(0.f, 0.f, 0.f, 0.f);
                 while (cand) {
                     const int k = __builtin_ctzll(cand);
                     cand &= cand - 1ULL;
-                    const float4 im = lds.imp[k];
-                    if (mine) {
-                        V3 to_point = pc - v3(im.x, im.y, im.z);
-                        if (length_sq(to_point) < 1.0f) {
-                            V3 ab = Rp - R * v3(im.x, im.y, im.z);
-                            V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
-                            float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
-                            float f = expf_glibc(-absq);
-                            if (GRAD)
-                                cell = cell + im.w * v4(f, -2.f * t.x * f, -2.f * t.y * f, -2.f * t.z * f);
-                            else
-                                cell.v = cell.v + im.w * f;
-                        }
+                    const float ix = lane_f(px, k), iy = lane_f(py, k), iz = lane_f(pz, k);
+                    V3 to_point = pc - v3(ix, iy, iz);
+                    if (mine && length_sq(to_point) < 1.0f) {
+                        const float iw = lane_f(pw, k);
+                        V3 ab = Rp - R * v3(ix, iy, iz);
+                        V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
+                        float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
+                        float f = expf_glibc_lds(lds, -absq);
+                        if (GRAD)
+                            cell = cell + iw * v4(f, -2.f * t.x * f, -2.f * t.y * f, -2.f * t.z * f);
+                        else
+                            cell.v = cell.v + iw * f;
                     }
                 }
                 if (mine) {
@@ -193,8 +234,10 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uin
 
 // evaluateNoise3D for the stationary single-realization case (SCN.cpp:101-116, 251-260, 291-320):
 // per-lane transforms exactly as the generic path, the noise3D sum cooperatively.
+// `coord` is the ray's isotropic-ray frame (SCN.cpp:296-297), constant along the segment and hoisted
+// out of the march by the caller.
 template <bool GRAD>
-GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, V3 rayDir, uint32_t &n_eval)
+GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
 {
     if (active) n_eval++;
     if (!M.iso3d) {
@@ -204,8 +247,6 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p
         V4 nz = coop_noise3d<GRAD>(M, lds, active, p, M.seed, R, A0, A1, A2);
         return nz / M.norm3d_world;
     }
-    V3 ray_dir_iso = normalized(cov_pos_w2l(M, rayDir, 1.0f));
-    Frame coord = frame_from_normal(ray_dir_iso);
     V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
     V4 nz = coop_noise3d<GRAD>(M, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f);
     if (GRAD) {
@@ -216,9 +257,9 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p
 }
 
 // evaluateValue, SCN.cpp:73-89
-GPIS_DEV float coop_evaluate_value(const DevModel &M, FastLds &lds, bool active, V3 p, V3 rayDir, int &gp_id, uint32_t &n_eval)
+GPIS_DEV float coop_evaluate_value(const DevModel &M, FastLds &lds, bool active, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
 {
-    float nv = coop_eval_noise3d<false>(M, lds, active, p, rayDir, n_eval).v;
+    float nv = coop_eval_noise3d<false>(M, lds, active, p, coord, n_eval).v;
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);
@@ -228,9 +269,9 @@ GPIS_DEV float coop_evaluate_value(const DevModel &M, FastLds &lds, bool active,
     return (float)((double)(M.sigma * nv) + mean);
 }
 // evaluateGradient, SCN.cpp:92-99
-GPIS_DEV V3 coop_evaluate_gradient(const DevModel &M, FastLds &lds, bool active, V3 p, V3 rayDir, uint32_t &n_eval)
+GPIS_DEV V3 coop_evaluate_gradient(const DevModel &M, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
 {
-    V4 nz = coop_eval_noise3d<true>(M, lds, active, p, rayDir, n_eval);
+    V4 nz = coop_eval_noise3d<true>(M, lds, active, p, coord, n_eval);
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);
@@ -258,6 +299,9 @@ GPIS_DEV void fast_march(const DevModel &M, FastLds &lds, bool valid, const gpis
     float step_size = (farT - nearT) / (float)M.min_step;
     if (M.step_size < step_size)
         step_size = M.step_size;
+    Frame coord{};
+    if (M.iso3d && valid)
+        coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
 
     int phase = PH_INIT;
     bool early_ok = false;         // maxT == 0 shortcut
@@ -280,7 +324,7 @@ GPIS_DEV void fast_march(const DevModel &M, FastLds &lds, bool valid, const gpis
         if (__ballot(want_val) == 0ULL)
             break;
         int gp_new;
-        float fv = coop_evaluate_value(M, lds, want_val, to_f(ray_at(p0, rd, t_query)), dir, gp_new, n_eval);
+        float fv = coop_evaluate_value(M, lds, want_val, to_f(ray_at(p0, rd, t_query)), coord, gp_new, n_eval);
         if (!want_val)
             continue;
         gp = gp_new;
@@ -361,7 +405,7 @@ GPIS_DEV void fast_march(const DevModel &M, FastLds &lds, bool valid, const gpis
     const bool want_grad = phase == PH_GRAD;
     V3 g = v3(0.f, 0.f, 0.f);
     if (__ballot(want_grad) != 0ULL)
-        g = coop_evaluate_gradient(M, lds, want_grad, to_f(ray_at(p0, rdn, t)), dir, n_eval);
+        g = coop_evaluate_gradient(M, lds, want_grad, to_f(ray_at(p0, rdn, t)), coord, n_eval);
     if (!valid)
         return;
 
@@ -442,6 +486,7 @@ __global__ void __launch_bounds__(kFastBlock) k_fast_sample_distance(const DevMo
                                                                     const uint8_t *__restrict__ mask, Counters *cnt)
 {
     __shared__ FastLds lds;
+    fast_lds_init(lds);
     size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
     const bool valid = i < n && (!mask || mask[i]);
     gpis_ray_in ray;
@@ -465,6 +510,7 @@ __global__ void __launch_bounds__(kFastBlock) k_fast_transmittance(const DevMode
                                                                   uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
 {
     __shared__ FastLds lds;
+    fast_lds_init(lds);
     size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
     const bool valid = i < n && (!mask || mask[i]);
     gpis_ray_in ray;
