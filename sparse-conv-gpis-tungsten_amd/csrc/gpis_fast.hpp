@@ -49,8 +49,14 @@ constexpr JumpTable make_jump_table()
 }
 __device__ const JumpTable kJump4 = make_jump_table();   // entry k: jump by 4k draws
 
+// Cell table in HBM (served from L2 / Infinity Cache): the impulses of every cell (i, j, k) with
+// -H <= i, j, k < H, as float4 (x, y, z, w=+-1) in generation order, `stride` slots per cell.  A wave
+// reads a cell with ONE coalesced 512-B / 1-KiB load; cells outside the table are generated on the
+// fly, so the table is a cache and never a correctness bound.
 struct FastTable {
-    float4 *cells;   // reserved for an HBM-resident cell cache; nullptr = cells are generated per wave
+    float4 *cells;   // nullptr = every cell is generated per wave
+    int half;        // H
+    int stride;      // 32 or 64 slots per cell
     int enabled;
 };
 
@@ -59,13 +65,65 @@ inline bool fast_supported(const DevModel &M)
     return M.single_realization && !M.sampling_1d && !M.nonstationary && !M.use_aniso_mtx && !M.absorption_only &&
            M.n_impulses >= 1 && M.n_impulses <= 64;
 }
+// one wave per cell: lane k produces impulse k exactly as the sequential generator (SCN.cpp:376-385)
+GPIS_DEV void gen_impulse(uint32_t ci, uint32_t cj, uint32_t ck, uint32_t seed, uint64_t jA, uint64_t jC,
+                          float &px, float &py, float &pz, float &pw)
+{
+    const uint32_t h = xxhash32_4(ck, cj, ci, seed) + 1u;
+    const uint64_t s0 = (uint64_t)h * (kPcgMult * kPcgMult) + (kPcgMult + 1ULL);   // set_state
+    Pcg32 g;
+    g.state = jA * s0 + jC;
+    pz = normalized_uint(g.next_i());
+    py = normalized_uint(g.next_i());
+    px = normalized_uint(g.next_i());
+    pw = (g.next_i() >> 31) ? 1.f : -1.f;   // Bernoulli(next1D(), -1, 1, 0.5)
+}
+__global__ void __launch_bounds__(64) k_fast_build_table(uint32_t seed, int half, int stride, float4 *__restrict__ cells)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int side = 2 * half;
+    const size_t cell = blockIdx.x;
+    const int ck = (int)(cell % side) - half, cj = (int)((cell / side) % side) - half, ci = (int)(cell / ((size_t)side * side)) - half;
+    float px, py, pz, pw;
+    gen_impulse((uint32_t)ci, (uint32_t)cj, (uint32_t)ck, seed, kJump4.A[lane], kJump4.C[lane], px, py, pz, pw);
+    if (lane < stride)
+        cells[cell * (size_t)stride + lane] = make_float4(px, py, pz, pw);
+}
 inline int fast_table_build(const DevModel &M, const DevModel *, FastTable *t)
 {
     t->cells = nullptr;
+    t->half = 0;
+    t->stride = 0;
     t->enabled = fast_supported(M) && !getenv("GPIS_DISABLE_FAST");
+    if (!t->enabled || getenv("GPIS_DISABLE_TABLE"))
+        return GPIS_OK;
+    int half = 16;   // covers |p| < 16 cells: scene S spans 14.2 cells (1.5 world units / cell size 0.106)
+    if (const char *e = getenv("GPIS_TABLE_HALF_EXTENT")) half = atoi(e);
+    if (half < 2) return GPIS_OK;
+    if (half > 40) half = 40;
+    const int stride = M.n_impulses <= 32 ? 32 : 64;
+    const size_t ncell = (size_t)(2 * half) * (2 * half) * (2 * half);
+    if (hipMalloc(&t->cells, ncell * stride * sizeof(float4)) != hipSuccess) {
+        t->cells = nullptr;   // no table: fall back to per-wave generation
+        (void)hipGetLastError();
+        return GPIS_OK;
+    }
+    k_fast_build_table<<<(unsigned)ncell, 64>>>(M.seed, half, stride, t->cells);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(t->cells);
+        t->cells = nullptr;
+        return GPIS_ERR_DEVICE;
+    }
+    t->half = half;
+    t->stride = stride;
     return GPIS_OK;
 }
-inline void fast_table_free(FastTable *t) { t->cells = nullptr; t->enabled = 0; }
+inline void fast_table_free(FastTable *t)
+{
+    if (t->cells) (void)hipFree(t->cells);
+    t->cells = nullptr;
+    t->enabled = 0;
+}
 
 // ---- wave reductions (wave64) ----------------------------------------------------------------
 GPIS_DEV float wave_min_f(float v)
@@ -135,7 +193,7 @@ GPIS_DEV V4 noise3d_per_lane(const DevModel &M, V3 p, uint32_t seed, float R, fl
 //   R      : kernelRadius (wave-uniform);  A0..A2: diagonal of getInvCovMtx (wave-uniform)
 // Returns (value, gradient) — gradient only when GRAD.
 template <bool GRAD>
-GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
+GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
 {
     const int lane = (int)(threadIdx.x & 63);
     V3 pg = p / R;
@@ -170,64 +228,79 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uin
 
     const uint32_t n = M.n_impulses;
     const uint64_t jA = kJump4.A[lane], jC = kJump4.C[lane];
+    // the union of the lanes' 3x3x3 neighbourhoods, walked in lexicographic (x, y, z) order
+    const int nj = jhi - jlo + 3, nk = khi - klo + 3;
+    const int total = (ihi - ilo + 3) * nj * nk;          // 27 .. 64 cells
+    const int H = T.half, S = T.stride;
+    const unsigned side = 2u * (unsigned)H;
+    const float4 *cells = T.cells;
+    auto in_table = [&](int ci, int cj, int ck) {
+        return cells && (unsigned)(ci + H) < side && (unsigned)(cj + H) < side && (unsigned)(ck + H) < side;
+    };
+    auto fetch = [&](int ci, int cj, int ck) {
+        const size_t idx = (((size_t)(ci + H) * side + (size_t)(cj + H)) * side + (size_t)(ck + H)) * (size_t)S;
+        return cells[idx + (size_t)(lane & (S - 1))];
+    };
+    int ci = ilo - 1, cj = jlo - 1, ck = klo - 1;
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_table(ci, cj, ck))
+        nxt = fetch(ci, cj, ck);
     V4 sum = v4(0.f, 0.f, 0.f, 0.f);
-    for (int ci = ilo - 1; ci <= ihi + 1; ++ci) {
-        const int di = ci - ci0;                              // per lane: this cell's dx
-        const float qx0 = bx0 - (float)ci, qx1 = bx1 - (float)ci;   // box of query points relative to the cell
-        for (int cj = jlo - 1; cj <= jhi + 1; ++cj) {
-            const int dj = cj - cj0;
-            const float qy0 = by0 - (float)cj, qy1 = by1 - (float)cj;
-            for (int ck = klo - 1; ck <= khi + 1; ++ck) {
-                const int dk = ck - ck0;
-                const bool mine = active && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
-                if (__ballot(mine) == 0ULL)
-                    continue;
-                const float qz0 = bz0 - (float)ck, qz1 = bz1 - (float)ck;
-                // --- generate impulse `lane` of this cell (SCN.cpp:376-385) ---
-                const uint32_t h = xxhash32_4((uint32_t)ck, (uint32_t)cj, (uint32_t)ci, seed) + 1u;
-                const uint64_t s0 = (uint64_t)h * (kPcgMult * kPcgMult) + (kPcgMult + 1ULL);   // set_state
-                Pcg32 g;
-                g.state = jA * s0 + jC;
-                float pz = normalized_uint(g.next_i());
-                float py = normalized_uint(g.next_i());
-                float px = normalized_uint(g.next_i());
-                float pw = (g.next_i() >> 31) ? 1.f : -1.f;
-                // sphere (radius 1) vs box-of-queries distance, with slack for the differently rounded test
-                float gx = fmaxf(fmaxf(qx0 - px, px - qx1), 0.f);
-                float gy = fmaxf(fmaxf(qy0 - py, py - qy1), 0.f);
-                float gz = fmaxf(fmaxf(qz0 - pz, pz - qz1), 0.f);
-                bool cand_k = (uint32_t)lane < n && (gx * gx + gy * gy + gz * gz) < 1.0001f;
-                unsigned long long cand = __ballot(cand_k);
-                if (cand == 0ULL)
-                    continue;
-                // --- consume (SCN.cpp:383-392), candidates in ascending k = the reference's order;
-                //     impulse k lives in lane k's registers and is broadcast with v_readlane ---
-                const V3 pc = frac - v3((float)di, (float)dj, (float)dk);
-                const V3 Rp = R * pc;
-                V4 cell = v4(0.f, 0.f, 0.f, 0.f);
-                while (cand) {
-                    const int k = __builtin_ctzll(cand);
-                    cand &= cand - 1ULL;
-                    const float ix = lane_f(px, k), iy = lane_f(py, k), iz = lane_f(pz, k);
-                    V3 to_point = pc - v3(ix, iy, iz);
-                    if (mine && length_sq(to_point) < 1.0f) {
-                        const float iw = lane_f(pw, k);
-                        V3 ab = Rp - R * v3(ix, iy, iz);
-                        V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
-                        float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
-                        float f = expf_glibc_lds(lds, -absq);
-                        if (GRAD)
-                            cell = cell + iw * v4(f, -2.f * t.x * f, -2.f * t.y * f, -2.f * t.z * f);
-                        else
-                            cell.v = cell.v + iw * f;
-                    }
-                }
-                if (mine) {
-                    if (GRAD) sum = sum + cell;
-                    else sum.v = sum.v + cell.v;
-                }
+    for (int c = 0; c < total; ++c) {
+        const int ti = ci, tj = cj, tk = ck;             // this cell
+        const float4 cur = nxt;
+        // advance (ci, cj, ck) and prefetch the next cell's impulses while this one is consumed
+        if (++ck > khi + 1) { ck = klo - 1; if (++cj > jhi + 1) { cj = jlo - 1; ++ci; } }
+        if (c + 1 < total && in_table(ci, cj, ck))
+            nxt = fetch(ci, cj, ck);
+        const int di = ti - ci0, dj = tj - cj0, dk = tk - ck0;
+        const bool mine = active && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
+        if (__ballot(mine) == 0ULL)
+            continue;
+        float px, py, pz, pw;
+        if (in_table(ti, tj, tk)) {
+            px = cur.x; py = cur.y; pz = cur.z; pw = cur.w;
+        } else {
+            gen_impulse((uint32_t)ti, (uint32_t)tj, (uint32_t)tk, seed, jA, jC, px, py, pz, pw);
+        }
+        // cull: sphere (radius 1) vs box-of-queries distance, with slack for the differently rounded test
+        const float qx0 = bx0 - (float)ti, qx1 = bx1 - (float)ti;
+        const float qy0 = by0 - (float)tj, qy1 = by1 - (float)tj;
+        const float qz0 = bz0 - (float)tk, qz1 = bz1 - (float)tk;
+        float gx = fmaxf(fmaxf(qx0 - px, px - qx1), 0.f);
+        float gy = fmaxf(fmaxf(qy0 - py, py - qy1), 0.f);
+        float gz = fmaxf(fmaxf(qz0 - pz, pz - qz1), 0.f);
+        bool cand_k = (uint32_t)lane < n && (gx * gx + gy * gy + gz * gz) < 1.0001f;
+        unsigned long long cand = __ballot(cand_k);
+        if (cand == 0ULL)
+            continue;
+        // --- consume (SCN.cpp:383-392), candidates in ascending k = the reference's order; impulse k
+        //     lives in lane k's registers and is broadcast with v_readlane ---
+        const float rx = R * px, ry = R * py, rz = R * pz;   // kernelRadius * p_i, once per impulse
+        const V3 pc_true = frac - v3((float)di, (float)dj, (float)dk);
+        const V3 Rp = R * pc_true;
+        // lanes whose neighbourhood does not contain this cell get a far-away point: the unit-ball
+        // test fails for them and their cell sum stays +0 (adding +0 is exact)
+        const V3 pc = mine ? pc_true : v3(8.f, 8.f, 8.f);
+        V4 cell = v4(0.f, 0.f, 0.f, 0.f);
+        while (cand) {
+            const int k = __builtin_ctzll(cand);
+            cand &= cand - 1ULL;
+            V3 to_point = pc - v3(lane_f(px, k), lane_f(py, k), lane_f(pz, k));
+            if (length_sq(to_point) < 1.0f) {
+                V3 ab = Rp - v3(lane_f(rx, k), lane_f(ry, k), lane_f(rz, k));
+                const float iw = lane_f(pw, k);
+                V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
+                float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
+                float f = expf_glibc_lds(lds, -absq);
+                if (GRAD)
+                    cell = cell + iw * v4(f, -2.f * t.x * f, -2.f * t.y * f, -2.f * t.z * f);
+                else
+                    cell.v = cell.v + iw * f;
             }
         }
+        if (GRAD) sum = sum + cell;
+        else sum.v = sum.v + cell.v;
     }
     return sum;
 }
@@ -237,18 +310,18 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, uin
 // `coord` is the ray's isotropic-ray frame (SCN.cpp:296-297), constant along the segment and hoisted
 // out of the march by the caller.
 template <bool GRAD>
-GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
+GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
 {
     if (active) n_eval++;
     if (!M.iso3d) {
         float R = M.radius_world;
         // getInvCovMtx(isCov=false, isIsotropic=false, globalScale=1, localScale=1): ((A / 1) / 1) * 0.5
         float A0 = M.invcov_world[0] / 1.f / 1.f * 0.5f, A1 = M.invcov_world[4] / 1.f / 1.f * 0.5f, A2 = M.invcov_world[8] / 1.f / 1.f * 0.5f;
-        V4 nz = coop_noise3d<GRAD>(M, lds, active, p, M.seed, R, A0, A1, A2);
+        V4 nz = coop_noise3d<GRAD>(M, T, lds, active, p, M.seed, R, A0, A1, A2);
         return nz / M.norm3d_world;
     }
     V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
-    V4 nz = coop_noise3d<GRAD>(M, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f);
+    V4 nz = coop_noise3d<GRAD>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f);
     if (GRAD) {
         V3 gw = cov_grad_l2w(M, to_global(coord, v3(nz.gx, nz.gy, nz.gz)), 1.0f);
         return v4(nz.v, gw.x, gw.y, gw.z) / M.norm3d_iso;
@@ -257,9 +330,9 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, FastLds &lds, bool active, V3 p
 }
 
 // evaluateValue, SCN.cpp:73-89
-GPIS_DEV float coop_evaluate_value(const DevModel &M, FastLds &lds, bool active, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
+GPIS_DEV float coop_evaluate_value(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
 {
-    float nv = coop_eval_noise3d<false>(M, lds, active, p, coord, n_eval).v;
+    float nv = coop_eval_noise3d<false>(M, T, lds, active, p, coord, n_eval).v;
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);
@@ -269,9 +342,9 @@ GPIS_DEV float coop_evaluate_value(const DevModel &M, FastLds &lds, bool active,
     return (float)((double)(M.sigma * nv) + mean);
 }
 // evaluateGradient, SCN.cpp:92-99
-GPIS_DEV V3 coop_evaluate_gradient(const DevModel &M, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
+GPIS_DEV V3 coop_evaluate_gradient(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
 {
-    V4 nz = coop_eval_noise3d<true>(M, lds, active, p, coord, n_eval);
+    V4 nz = coop_eval_noise3d<true>(M, T, lds, active, p, coord, n_eval);
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);
@@ -285,7 +358,7 @@ enum Phase : int { PH_INIT = 0, PH_MARCH = 1, PH_REFINE = 2, PH_FINAL = 3, PH_GR
 // transmittance (GPM.cpp:343-393), whose result does not depend on the end-of-segment gradient nor
 // on lastVal, so those two evaluations are not performed.
 template <bool WANT_SAMPLE>
-GPIS_DEV void fast_march(const DevModel &M, FastLds &lds, bool valid, const gpis_ray_in &ray, gpis_seg_out *out, bool &visible, uint32_t &n_eval)
+GPIS_DEV void fast_march(const DevModel &M, const FastTable &T, FastLds &lds, bool valid, const gpis_ray_in &ray, gpis_seg_out *out, bool &visible, uint32_t &n_eval)
 {
     V3 pos = v3(ray.pos[0], ray.pos[1], ray.pos[2]), dir = v3(ray.dir[0], ray.dir[1], ray.dir[2]);
     float nearT = ray.near_t, farT = ray.far_t;
@@ -324,7 +397,7 @@ GPIS_DEV void fast_march(const DevModel &M, FastLds &lds, bool valid, const gpis
         if (__ballot(want_val) == 0ULL)
             break;
         int gp_new;
-        float fv = coop_evaluate_value(M, lds, want_val, to_f(ray_at(p0, rd, t_query)), coord, gp_new, n_eval);
+        float fv = coop_evaluate_value(M, T, lds, want_val, to_f(ray_at(p0, rd, t_query)), coord, gp_new, n_eval);
         if (!want_val)
             continue;
         gp = gp_new;
@@ -405,7 +478,7 @@ GPIS_DEV void fast_march(const DevModel &M, FastLds &lds, bool valid, const gpis
     const bool want_grad = phase == PH_GRAD;
     V3 g = v3(0.f, 0.f, 0.f);
     if (__ballot(want_grad) != 0ULL)
-        g = coop_evaluate_gradient(M, lds, want_grad, to_f(ray_at(p0, rdn, t)), coord, n_eval);
+        g = coop_evaluate_gradient(M, T, lds, want_grad, to_f(ray_at(p0, rdn, t)), coord, n_eval);
     if (!valid)
         return;
 
@@ -481,7 +554,7 @@ __device__ __forceinline__ void fast_flush_counters(Counters *cnt, uint32_t n_ev
     }
 }
 
-__global__ void __launch_bounds__(kFastBlock) k_fast_sample_distance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+__global__ void __launch_bounds__(kFastBlock, 3) k_fast_sample_distance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
                                                                     gpis_seg_out *__restrict__ out, gpis_cond_coeff *__restrict__ coeff,
                                                                     const uint8_t *__restrict__ mask, Counters *cnt)
 {
@@ -496,7 +569,7 @@ __global__ void __launch_bounds__(kFastBlock) k_fast_sample_distance(const DevMo
     bool vis;
     gpis_seg_out *o = valid ? &out[i] : nullptr;
     gpis_seg_out tmp;
-    fast_march<true>(*Mp, lds, valid, ray, valid ? o : &tmp, vis, n_eval);
+    fast_march<true>(*Mp, T, lds, valid, ray, valid ? o : &tmp, vis, n_eval);
     if (valid && coeff) {
         gpis_cond_coeff c;
         memset(&c, 0, sizeof c);
@@ -506,7 +579,7 @@ __global__ void __launch_bounds__(kFastBlock) k_fast_sample_distance(const DevMo
     fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
 }
 
-__global__ void __launch_bounds__(kFastBlock) k_fast_transmittance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+__global__ void __launch_bounds__(kFastBlock, 3) k_fast_transmittance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
                                                                   uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
 {
     __shared__ FastLds lds;
@@ -518,24 +591,24 @@ __global__ void __launch_bounds__(kFastBlock) k_fast_transmittance(const DevMode
     else memset(&ray, 0, sizeof ray);
     uint32_t n_eval = 0;
     bool vis = false;
-    fast_march<false>(*Mp, lds, valid, ray, nullptr, vis, n_eval);
+    fast_march<false>(*Mp, T, lds, valid, ray, nullptr, vis, n_eval);
     if (i < n)
         visible[i] = (valid && vis) ? 1 : 0;
     fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
 }
 
-inline int fast_sample_distance(const DevModel *d_model, const FastTable *, size_t n, const gpis_ray_in *rays, gpis_seg_out *out,
+inline int fast_sample_distance(const DevModel *d_model, const FastTable *T, size_t n, const gpis_ray_in *rays, gpis_seg_out *out,
                                 gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, hipStream_t s)
 {
     unsigned grid = (unsigned)((n + kFastBlock - 1) / kFastBlock);
-    k_fast_sample_distance<<<grid, kFastBlock, 0, s>>>(d_model, n, rays, out, coeff, mask, cnt);
+    k_fast_sample_distance<<<grid, kFastBlock, 0, s>>>(d_model, *T, n, rays, out, coeff, mask, cnt);
     return GPIS_OK;
 }
-inline int fast_transmittance(const DevModel *d_model, const FastTable *, size_t n, const gpis_ray_in *rays, uint8_t *visible,
+inline int fast_transmittance(const DevModel *d_model, const FastTable *T, size_t n, const gpis_ray_in *rays, uint8_t *visible,
                               const uint8_t *mask, Counters *cnt, hipStream_t s)
 {
     unsigned grid = (unsigned)((n + kFastBlock - 1) / kFastBlock);
-    k_fast_transmittance<<<grid, kFastBlock, 0, s>>>(d_model, n, rays, visible, mask, cnt);
+    k_fast_transmittance<<<grid, kFastBlock, 0, s>>>(d_model, *T, n, rays, visible, mask, cnt);
     return GPIS_OK;
 }
 

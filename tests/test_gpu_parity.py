@@ -86,22 +86,33 @@ def test_eval_value_gradient_bit_exact(env, cfg):
     assert e_g >= 2 * len(q)
 
 
+PATHS = ["fast", "fast_gen", "fast_small_table", "generic"]
+
+
 def _medium(pkg, params, path):
-    """path 'fast': the wave-cooperative single-realization kernels; 'generic': lane-per-ray kernels."""
+    """Kernel path under test:
+      fast             wave-cooperative kernels, cell impulses read from the HBM table
+      fast_gen         wave-cooperative kernels, every cell generated on the fly (no table)
+      fast_small_table a 4-cell half-extent table: most cells of scene S fall outside it, so table
+                       cells and generated cells are mixed inside one evaluation
+      generic          lane-per-ray kernels"""
     import os
-    if path == "generic":
-        os.environ["GPIS_DISABLE_FAST"] = "1"
-    else:
-        os.environ.pop("GPIS_DISABLE_FAST", None)
+    env = {"generic": {"GPIS_DISABLE_FAST": "1"}, "fast_gen": {"GPIS_DISABLE_TABLE": "1"},
+           "fast_small_table": {"GPIS_TABLE_HALF_EXTENT": "4"}, "fast": {}}[path]
+    keys = ("GPIS_DISABLE_FAST", "GPIS_DISABLE_TABLE", "GPIS_TABLE_HALF_EXTENT")
+    for k in keys:
+        os.environ.pop(k, None)
+    os.environ.update(env)
     try:
         med = pkg.Medium(params)
     finally:
-        os.environ.pop("GPIS_DISABLE_FAST", None)
-    assert int(med.derived()["fast_path"]) == (1 if path == "fast" else 0)
+        for k in keys:
+            os.environ.pop(k, None)
+    assert int(med.derived()["fast_path"]) == (0 if path == "generic" else 1)
     return med
 
 
-@pytest.mark.parametrize("path", ["fast", "generic"])
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("cfg,res,step", [("C0", (256, 256), 5), ("C1", (480, 270), 7)])
 def test_march_bit_exact(env, cfg, res, step, path):
     pkg, ob, lib = env
@@ -125,7 +136,7 @@ def test_march_bit_exact(env, cfg, res, step, path):
     assert np.array_equal(to_host(d_o, pkg.SEG_OUT), got)
 
 
-@pytest.mark.parametrize("path", ["fast", "generic"])
+@pytest.mark.parametrize("path", PATHS)
 def test_march_edge_cases(env, path):
     pkg, ob, lib = env
     params = pkg.params_for_config("C1")
@@ -361,7 +372,7 @@ def test_derived_constants_match(env):
             assert np.array_equal(d_g[f], d_o[f]), (cfg, f)
 
 
-@pytest.mark.parametrize("path", ["fast", "generic"])
+@pytest.mark.parametrize("path", PATHS)
 def test_incoherent_and_ragged_waves(env, path):
     """Rays in random order / random directions (waves whose lanes share no cells), batches that are
     not a multiple of 64, and neighbouring lanes straddling cell boundaries."""
@@ -396,7 +407,7 @@ def test_incoherent_and_ragged_waves(env, path):
         assert 0 < (want["exited"] == 0).sum() < n
 
 
-@pytest.mark.parametrize("path", ["fast", "generic"])
+@pytest.mark.parametrize("path", PATHS)
 def test_render_scene_s_small(env, path):
     """Whole estimator (ray generation → sampleDistance → shading → shadow transmittance → per-pixel sum)."""
     import torch
