@@ -137,7 +137,25 @@ GPIS_DEV float wave_max_f(float v)
     return v;
 }
 
+// Diagnostic build only (-DGPIS_FAST_STATS): wave-level work counters of the cooperative loop.
+// -DGPIS_DUP=k duplicates one part of the loop (result kept alive, outputs unchanged) so that
+// t(dup k) - t(base) prices that part without changing control flow:
+//   1 expf   2 whole body   3 unit-ball test   4 per-cell load + cull   5 per-evaluation prologue
+#ifndef GPIS_DUP
+#define GPIS_DUP 0
+#endif
+#define GPIS_KEEP(x) asm volatile("" ::"v"(x))
+#ifdef GPIS_FAST_STATS
+__device__ unsigned long long g_fast_stats[16];
+#define FSTAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fast_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define FSTAT(i, v) do { } while (0)
+#endif
+
 constexpr int kFastBlock = 64;          // one wave per workgroup
+#ifndef GPIS_FAST_OCC
+#define GPIS_FAST_OCC 3                 // waves per SIMD the register allocator must leave room for
+#endif
 struct FastLds {
     uint64_t exptab[32];                // glibc's exp2f table, staged once per wave (ds_read_b64 per use)
 };
@@ -208,6 +226,17 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
     const float bz0 = uni_f(wave_min_f(active ? pg.z : big)), bz1 = uni_f(wave_max_f(active ? pg.z : -big));
     if (!(bx0 <= bx1))
         return v4(0.f, 0.f, 0.f, 0.f);   // no active lane in this wave
+#if GPIS_DUP == 5
+    {
+        V3 pg2 = (p + v3(1e-3f, 1e-3f, 1e-3f)) / R;
+        float a0 = uni_f(wave_min_f(active ? pg2.x : big)), a1 = uni_f(wave_max_f(active ? pg2.x : -big));
+        float b0 = uni_f(wave_min_f(active ? pg2.y : big)), b1 = uni_f(wave_max_f(active ? pg2.y : -big));
+        float c0 = uni_f(wave_min_f(active ? pg2.z : big)), c1 = uni_f(wave_max_f(active ? pg2.z : -big));
+        GPIS_KEEP(a0 + a1 + b0 + b1 + c0 + c1 + floorf(pg2.x) + floorf(pg2.y) + floorf(pg2.z));
+    }
+#endif
+    FSTAT(0, 1);
+    FSTAT(1, __popcll(__ballot(active)));
     // cells are addressed with int coordinates; keep far away from overflow and from float→int UB
     const float lim = 1.0e6f;
     bool sane = bx0 > -lim && bx1 < lim && by0 > -lim && by1 < lim && bz0 > -lim && bz1 < lim;
@@ -221,13 +250,13 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
     if (!coherent) {
         // incoherent wave (or non-finite input): every lane generates its own impulses
         V4 r = v4(0.f, 0.f, 0.f, 0.f);
+        FSTAT(8, 1);
         if (active)
             r = noise3d_per_lane(M, p, seed, R, A0, A1, A2);
         return r;
     }
 
     const uint32_t n = M.n_impulses;
-    const uint64_t jA = kJump4.A[lane], jC = kJump4.C[lane];
     // the union of the lanes' 3x3x3 neighbourhoods, walked in lexicographic (x, y, z) order
     const int nj = jhi - jlo + 3, nk = khi - klo + 3;
     const int total = (ihi - ilo + 3) * nj * nk;          // 27 .. 64 cells
@@ -255,13 +284,15 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
             nxt = fetch(ci, cj, ck);
         const int di = ti - ci0, dj = tj - cj0, dk = tk - ck0;
         const bool mine = active && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
+        FSTAT(2, 1);
         if (__ballot(mine) == 0ULL)
             continue;
+        FSTAT(3, 1);
         float px, py, pz, pw;
         if (in_table(ti, tj, tk)) {
             px = cur.x; py = cur.y; pz = cur.z; pw = cur.w;
         } else {
-            gen_impulse((uint32_t)ti, (uint32_t)tj, (uint32_t)tk, seed, jA, jC, px, py, pz, pw);
+            gen_impulse((uint32_t)ti, (uint32_t)tj, (uint32_t)tk, seed, kJump4.A[lane], kJump4.C[lane], px, py, pz, pw);
         }
         // cull: sphere (radius 1) vs box-of-queries distance, with slack for the differently rounded test
         const float qx0 = bx0 - (float)ti, qx1 = bx1 - (float)ti;
@@ -272,31 +303,61 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
         float gz = fmaxf(fmaxf(qz0 - pz, pz - qz1), 0.f);
         bool cand_k = (uint32_t)lane < n && (gx * gx + gy * gy + gz * gz) < 1.0001f;
         unsigned long long cand = __ballot(cand_k);
+#if GPIS_DUP == 4
+        {
+            float4 e = in_table(ti, tj, tk) ? fetch(ti, tj, tk ^ 1) : make_float4(px, py, pz, pw);
+            float hx = fmaxf(fmaxf(qx0 - e.x, e.x - qx1), 0.f), hy = fmaxf(fmaxf(qy0 - e.y, e.y - qy1), 0.f), hz = fmaxf(fmaxf(qz0 - e.z, e.z - qz1), 0.f);
+            unsigned long long c2 = __ballot((uint32_t)lane < n && (hx * hx + hy * hy + hz * hz) < 1.0001f);
+            GPIS_KEEP((float)(unsigned)(c2 >> 7) + R * e.x + R * e.y + R * e.z);
+        }
+#endif
         if (cand == 0ULL)
             continue;
-        // --- consume (SCN.cpp:383-392), candidates in ascending k = the reference's order; impulse k
-        //     lives in lane k's registers and is broadcast with v_readlane ---
+        FSTAT(4, 1);
+        FSTAT(5, __popcll(cand));
+        // --- consume (SCN.cpp:383-392), candidates in ascending k = the reference's order.  Impulse k
+        //     lives in lane k's registers and is broadcast with v_readlane; every broadcast sits in
+        //     wave-uniform control flow (a lane that is masked off may have had its registers spilled
+        //     and not restored).  The body is branch-free: a lane whose unit-ball test fails adds +0,
+        //     which is exact, so two candidates can be in flight at once (independent f64 chains).
         const float rx = R * px, ry = R * py, rz = R * pz;   // kernelRadius * p_i, once per impulse
-        const V3 pc_true = frac - v3((float)di, (float)dj, (float)dk);
-        const V3 Rp = R * pc_true;
         // lanes whose neighbourhood does not contain this cell get a far-away point: the unit-ball
-        // test fails for them and their cell sum stays +0 (adding +0 is exact)
-        const V3 pc = mine ? pc_true : v3(8.f, 8.f, 8.f);
+        // test fails for them and their cell sum stays +0
+        const V3 pc = mine ? frac - v3((float)di, (float)dj, (float)dk) : v3(8.f, 8.f, 8.f);
+        const V3 Rp = R * pc;
+        auto contribution = [&](int k) {
+            const float ix = lane_f(px, k), iy = lane_f(py, k), iz = lane_f(pz, k), iw = lane_f(pw, k);
+            const float jx = lane_f(rx, k), jy = lane_f(ry, k), jz = lane_f(rz, k);
+            const bool pass = length_sq(pc - v3(ix, iy, iz)) < 1.0f;
+            const V3 ab = Rp - v3(jx, jy, jz);
+            const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
+            const float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
+            const float f = expf_glibc_lds(lds, -absq);
+            V4 r;
+            r.v = pass ? iw * f : 0.f;
+            if (GRAD) {
+                r.gx = pass ? iw * (-2.f * t.x * f) : 0.f;
+                r.gy = pass ? iw * (-2.f * t.y * f) : 0.f;
+                r.gz = pass ? iw * (-2.f * t.z * f) : 0.f;
+            } else {
+                r.gx = r.gy = r.gz = 0.f;
+            }
+            return r;
+        };
         V4 cell = v4(0.f, 0.f, 0.f, 0.f);
         while (cand) {
-            const int k = __builtin_ctzll(cand);
+            const int k0 = __builtin_ctzll(cand);
             cand &= cand - 1ULL;
-            V3 to_point = pc - v3(lane_f(px, k), lane_f(py, k), lane_f(pz, k));
-            if (length_sq(to_point) < 1.0f) {
-                V3 ab = Rp - v3(lane_f(rx, k), lane_f(ry, k), lane_f(rz, k));
-                const float iw = lane_f(pw, k);
-                V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
-                float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
-                float f = expf_glibc_lds(lds, -absq);
-                if (GRAD)
-                    cell = cell + iw * v4(f, -2.f * t.x * f, -2.f * t.y * f, -2.f * t.z * f);
-                else
-                    cell.v = cell.v + iw * f;
+            if (cand) {
+                const int k1 = __builtin_ctzll(cand);
+                cand &= cand - 1ULL;
+                const V4 c0 = contribution(k0), c1 = contribution(k1);
+                if (GRAD) cell = (cell + c0) + c1;
+                else cell.v = (cell.v + c0.v) + c1.v;
+            } else {
+                const V4 c0 = contribution(k0);
+                if (GRAD) cell = cell + c0;
+                else cell.v = cell.v + c0.v;
             }
         }
         if (GRAD) sum = sum + cell;
@@ -357,84 +418,84 @@ enum Phase : int { PH_INIT = 0, PH_MARCH = 1, PH_REFINE = 2, PH_FINAL = 3, PH_GR
 // The march of one wave of segments.  WANT_SAMPLE: sampleDistance (GPM.cpp:221-341) — otherwise
 // transmittance (GPM.cpp:343-393), whose result does not depend on the end-of-segment gradient nor
 // on lastVal, so those two evaluations are not performed.
+// Register diet: only what the lockstep loop needs stays live (floats for pos/dir, widened on use
+// exactly as `vec_conv<Vec3d>` does; pass-through fields are re-read from the ray at the end).
 template <bool WANT_SAMPLE>
-GPIS_DEV void fast_march(const DevModel &M, const FastTable &T, FastLds &lds, bool valid, const gpis_ray_in &ray, gpis_seg_out *out, bool &visible, uint32_t &n_eval)
+GPIS_DEV void fast_march(const DevModel &M, const FastTable &T, FastLds &lds, bool valid, const gpis_ray_in *__restrict__ rayp,
+                         gpis_seg_out *out, bool &visible, uint32_t &n_eval)
 {
-    V3 pos = v3(ray.pos[0], ray.pos[1], ray.pos[2]), dir = v3(ray.dir[0], ray.dir[1], ray.dir[2]);
-    float nearT = ray.near_t, farT = ray.far_t;
+    V3 pos = v3(0.f, 0.f, 1.f), dir = v3(0.f, 0.f, 1.f);
+    float nearT = 0.f, farT = 1.f, u_jitter = 0.f;
+    bool first_scatter = true;
+    int bounce = 0;
+    if (valid) {
+        pos = v3(rayp->pos[0], rayp->pos[1], rayp->pos[2]);
+        dir = v3(rayp->dir[0], rayp->dir[1], rayp->dir[2]);
+        nearT = rayp->near_t; farT = rayp->far_t; u_jitter = rayp->u_jitter;
+        first_scatter = rayp->first_scatter != 0;
+        bounce = rayp->bounce;
+    }
     if (!__builtin_isfinite(farT))
         farT = (float)((double)nearT + 2000);
-    const float maxT = farT;
-    const bool first_scatter = ray.first_scatter != 0;
-    const V3d p0 = to_d(pos), rd = to_d(dir);
-    V3d rdn = rd;
-    { double inv = 1.0 / length_d(rd); rdn.x *= inv; rdn.y *= inv; rdn.z *= inv; }
     float step_size = (farT - nearT) / (float)M.min_step;
     if (M.step_size < step_size)
         step_size = M.step_size;
     Frame coord{};
-    if (M.iso3d && valid)
+    if (M.iso3d)
         coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
 
     int phase = PH_INIT;
     bool early_ok = false;         // maxT == 0 shortcut
     if (!valid)
         phase = PH_DONE;
-    else if (WANT_SAMPLE && ray.bounce >= M.max_bounces)
+    else if (WANT_SAMPLE && bounce >= M.max_bounces)
         phase = PH_DONE;
-    else if (WANT_SAMPLE && maxT == 0.f) {
+    else if (WANT_SAMPLE && farT == 0.f) {
         phase = PH_DONE;
         early_ok = true;
     }
-    double t = (double)nearT, pf = 0., a_lo = 0., intp = 0., t_test = 0., t_prev = 0.;
-    int sign0 = 1, step = 0, gp = ray.last_gp_id;
-    float last_val = ray.last_val;
+    // t: march position (PH_MARCH) / result; refinement bracket [a_lo, t] with factor intp
+    double t = (double)nearT, a_lo = 0., intp = 0., t_test = 0., t_prev = 0.;
+    float pf = 0.f;                // previous field value (a float widened on use, SCNM.cpp:128,172)
+    int sign0 = 1, step = 0, gp = 0;
+    float last_val = 0.f;
     bool hit = false;
-    double t_query = (double)nearT;
 
     for (;;) {
         const bool want_val = phase <= PH_FINAL;
         if (__ballot(want_val) == 0ULL)
             break;
+        const double tq = phase == PH_INIT ? (double)nearT : (phase == PH_REFINE ? t_test : (phase == PH_FINAL ? (double)farT : t));
         int gp_new;
-        float fv = coop_evaluate_value(M, T, lds, want_val, to_f(ray_at(p0, rd, t_query)), coord, gp_new, n_eval);
+        float fv = coop_evaluate_value(M, T, lds, want_val, to_f(ray_at(to_d(pos), to_d(dir), tq)), coord, gp_new, n_eval);
         if (!want_val)
             continue;
         gp = gp_new;
         const double f = (double)fv;
         if (phase == PH_INIT) {
             sign0 = f < 0 ? -1 : 1;
-            pf = f;
-            t = (double)(nearT + step_size * ray.u_jitter);
+            pf = fv;
+            t = (double)(nearT + step_size * u_jitter);
             phase = (t < (double)farT) ? PH_MARCH : PH_FINAL;
-            t_query = phase == PH_MARCH ? t : (double)farT;
         } else if (phase == PH_MARCH) {
             step++;
             const int signc = f < 0 ? -1 : 1;
             if (!first_scatter && step == 1) {
                 sign0 = signc;
-                pf = f;
+                pf = fv;
                 t += (double)step_size;
             } else if (signc != sign0) {
-                intp = pf / (pf - f);
+                intp = (double)pf / ((double)pf - f);
                 a_lo = t - (double)step_size;
                 t_prev = lerp_d(a_lo, t, intp);
                 t_test = t_prev;
                 phase = PH_REFINE;
             } else {
-                pf = f;
+                pf = fv;
                 t += (double)step_size;
             }
-            if (phase == PH_MARCH) {
-                if (t < (double)farT) {
-                    t_query = t;
-                } else {
-                    phase = PH_FINAL;
-                    t_query = (double)farT;
-                }
-            } else {
-                t_query = t_test;
-            }
+            if (phase == PH_MARCH && !(t < (double)farT))
+                phase = PH_FINAL;
         } else if (phase == PH_REFINE) {
             const int sign_test = f < 0 ? -1 : 1;
             bool done = false;
@@ -448,7 +509,6 @@ GPIS_DEV void fast_march(const DevModel &M, const FastTable &T, FastLds &lds, bo
                 } else {
                     t_prev = t_test;
                     t_test = lerp_d(a_lo, t, intp);
-                    t_query = t_test;
                 }
             }
             if (done) {
@@ -474,22 +534,27 @@ GPIS_DEV void fast_march(const DevModel &M, const FastTable &T, FastLds &lds, bo
     if (!WANT_SAMPLE)
         return;
 
-    // one gradient evaluation per segment (GPM.cpp:283 on a hit, GPM.cpp:319 on exit)
+    // one gradient evaluation per segment (GPM.cpp:283 on a hit, GPM.cpp:319 on exit), at
+    // ro + normalize(rd) * t (GPM.cpp:262-263, 280)
     const bool want_grad = phase == PH_GRAD;
     V3 g = v3(0.f, 0.f, 0.f);
-    if (__ballot(want_grad) != 0ULL)
-        g = coop_evaluate_gradient(M, T, lds, want_grad, to_f(ray_at(p0, rdn, t)), coord, n_eval);
+    if (__ballot(want_grad) != 0ULL) {
+        V3d rdn = to_d(dir);
+        { double inv = 1.0 / length_d(rdn); rdn.x *= inv; rdn.y *= inv; rdn.z *= inv; }
+        g = coop_evaluate_gradient(M, T, lds, want_grad, to_f(ray_at(to_d(pos), rdn, t)), coord, n_eval);
+    }
     if (!valid)
         return;
 
+    const float maxT = farT;
     gpis_seg_out o;
     o.t = 0.;
     o.sample_t = 0.f; o.continued_t = 0.f;
     for (int c = 0; c < 3; ++c) { o.weight[c] = 0.f; o.continued_weight[c] = 0.f; o.p[c] = 0.f; }
     o.exited = 0; o.ok = 0; o.scheme = GPIS_UNI;
-    o.gp_id = ray.last_gp_id;
-    o.last_val = ray.last_val;
-    o.aniso[0] = ray.last_aniso[0]; o.aniso[1] = ray.last_aniso[1]; o.aniso[2] = ray.last_aniso[2];
+    o.gp_id = rayp->last_gp_id;
+    o.last_val = rayp->last_val;
+    o.aniso[0] = rayp->last_aniso[0]; o.aniso[1] = rayp->last_aniso[1]; o.aniso[2] = rayp->last_aniso[2];
     if (early_ok) {
         o.weight[0] = o.weight[1] = o.weight[2] = 1.f;
         o.exited = 1;
@@ -554,7 +619,7 @@ __device__ __forceinline__ void fast_flush_counters(Counters *cnt, uint32_t n_ev
     }
 }
 
-__global__ void __launch_bounds__(kFastBlock, 3) k_fast_sample_distance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
+__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_fast_sample_distance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
                                                                     gpis_seg_out *__restrict__ out, gpis_cond_coeff *__restrict__ coeff,
                                                                     const uint8_t *__restrict__ mask, Counters *cnt)
 {
@@ -562,14 +627,9 @@ __global__ void __launch_bounds__(kFastBlock, 3) k_fast_sample_distance(const De
     fast_lds_init(lds);
     size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
     const bool valid = i < n && (!mask || mask[i]);
-    gpis_ray_in ray;
-    if (valid) ray = rays[i];
-    else memset(&ray, 0, sizeof ray);
     uint32_t n_eval = 0;
     bool vis;
-    gpis_seg_out *o = valid ? &out[i] : nullptr;
-    gpis_seg_out tmp;
-    fast_march<true>(*Mp, T, lds, valid, ray, valid ? o : &tmp, vis, n_eval);
+    fast_march<true>(*Mp, T, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval);
     if (valid && coeff) {
         gpis_cond_coeff c;
         memset(&c, 0, sizeof c);
@@ -579,19 +639,16 @@ __global__ void __launch_bounds__(kFastBlock, 3) k_fast_sample_distance(const De
     fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
 }
 
-__global__ void __launch_bounds__(kFastBlock, 3) k_fast_transmittance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
+__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_fast_transmittance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
                                                                   uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
 {
     __shared__ FastLds lds;
     fast_lds_init(lds);
     size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
     const bool valid = i < n && (!mask || mask[i]);
-    gpis_ray_in ray;
-    if (valid) ray = rays[i];
-    else memset(&ray, 0, sizeof ray);
     uint32_t n_eval = 0;
     bool vis = false;
-    fast_march<false>(*Mp, T, lds, valid, ray, nullptr, vis, n_eval);
+    fast_march<false>(*Mp, T, lds, valid, rays + (valid ? i : 0), nullptr, vis, n_eval);
     if (i < n)
         visible[i] = (valid && vis) ? 1 : 0;
     fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);

@@ -886,6 +886,20 @@ extern "C" int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_
     return GPIS_OK;
 }
 
+#ifdef GPIS_FAST_STATS
+// diagnostic build only: read and clear the cooperative loop's work counters
+extern "C" int gpis_debug_fast_stats(uint64_t *out16)
+{
+    unsigned long long h[16];
+    if (hipDeviceSynchronize() != hipSuccess) return GPIS_ERR_DEVICE;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gpis::g_fast_stats), sizeof h) != hipSuccess) return GPIS_ERR_DEVICE;
+    for (int i = 0; i < 16; ++i) out16[i] = h[i];
+    memset(h, 0, sizeof h);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gpis::g_fast_stats), h, sizeof h) != hipSuccess) return GPIS_ERR_DEVICE;
+    return GPIS_OK;
+}
+#endif
+
 // ---- scene S driver ----------------------------------------------------------------------
 extern "C" void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp)
 {

@@ -1,0 +1,31 @@
+"""Diagnostic (GPU box only): builds the library with -DGPIS_FAST_STATS into gpurun_out/ and prints the
+wave-level work counters of the cooperative loop for a small scene-S render."""
+import ctypes, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _gpis_pkg
+pkg = _gpis_pkg.load_package()
+so = os.path.join(ROOT, "gpurun_out", "libgpis_hip_stats.so")
+csrc = os.path.join(ROOT, "sparse-conv-gpis-tungsten_amd", "csrc")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                       "-DGPIS_FAST_STATS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so, os.path.join(csrc, "gpis_hip.hip")])
+import torch
+lib = pkg.GpisLib(so)
+w, h, spp = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (480, 270, 64)))
+med = pkg.Medium(pkg.params_for_config(sys.argv[4] if len(sys.argv) > 4 else "C1"), lib=lib)
+scene = np.zeros((), dtype=pkg.SCENE_S)
+lib.lib.gpis_default_scene_s(scene.ctypes.data, w, h, spp)
+rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, None)
+torch.cuda.synchronize()
+out = (ctypes.c_uint64 * 16)()
+lib.lib.gpis_debug_fast_stats(out)
+names = ["wave_evals", "active_lanes", "cells_visited", "cells_mine", "cells_cand", "candidates", "union_pass", "lane_pass", "incoherent"]
+st = dict(zip(names, list(out)))
+e = max(st["wave_evals"], 1)
+print(st)
+print("per wave-eval: active lanes %.1f, cells visited %.1f, processed %.1f, with candidates %.1f, candidates %.1f, bodies %.1f, "
+      "lane-passes/body %.1f, incoherent %.4f" % (st["active_lanes"] / e, st["cells_visited"] / e, st["cells_mine"] / e, st["cells_cand"] / e,
+                                                 st["candidates"] / e, st["union_pass"] / e, st["lane_pass"] / max(st["union_pass"], 1), st["incoherent"] / e))
+print("lane evals", med.counters())
