@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--shard", choices=["spp", "rows"], default="spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -114,25 +115,24 @@ def main():
 
     # rank 0 owns the scene/kernel parameters; broadcast the POD block over RCCL
     params = pkg.params_for_config(args.config) if rank == 0 else np.zeros((), dtype=pkg.PARAMS)
-    if world > 1:
-        blob = torch.from_numpy(np.frombuffer(params.tobytes(), dtype=np.uint8).copy()).cuda()
-        dist.broadcast(blob, src=0)
-        params = np.frombuffer(blob.cpu().numpy().tobytes(), dtype=pkg.PARAMS)[0].copy()
+    params = pkg.dist.broadcast_params(params, pkg.PARAMS, dist, device="cuda")
 
     med = pkg.Medium(params, device=local_rank)
     lib = med.L.lib
     W, H, spp = args.width, args.height, args.spp
     scene = np.zeros((), dtype=pkg.SCENE_S)
     lib.gpis_default_scene_s(scene.ctypes.data, W, H, spp)
-    scene["spp_begin"] = rank * spp          # weak scaling: each rank renders its own spp slice
     rad = torch.zeros(H * W, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    def render_into(part, acc):
+        med.call("gpis_render_scene_s", part.ctypes.data_as(ctypes.c_void_p), acc.data_ptr(), None, stream)
+
     def step():
         rad.zero_()
-        med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, stream)
-        if world > 1:
-            dist.reduce(rad, dst=0, op=dist.ReduceOp.SUM)
+        # weak scaling ("spp"): each rank renders its own spp slice of every pixel, then one
+        # reduce(sum) to rank 0; "rows" deals 16-pixel tile rows round-robin (strong scaling)
+        pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard)
 
     def fence():
         if world > 1:
@@ -159,7 +159,7 @@ def main():
 
     prof = [med.kernel_profile(k) for k in (0, 1)]     # (ms, launches, n_eval, n_seg)
     if rank == 0:
-        total_samples = W * H * spp * world * args.steps
+        total_samples = W * H * pkg.dist.total_spp(scene, world, args.shard) * args.steps
         b_eval = algorithmic_bytes_per_eval(params)
         names = ("sample_distance", "transmittance")
         dom = 0 if prof[0][0] >= prof[1][0] else 1
@@ -171,11 +171,11 @@ def main():
         res = {
             "metric": "Msamples/s (primary rays x spp / s)", "value": total_samples / dt_max / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if args.shard == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: scene S %dx%d, %d spp/GPU, SparseConvolutionNoiseMedium (3D isotropic, "
                                    "impulse_density=%d, ctx=renewal, single_realization)" % (args.config, W, H, spp, int(params["impulse_density"]))
                        if args.config == "C1" else "%s: scene S %dx%d, %d spp/GPU" % (args.config, W, H, spp),
-                       "sharding": "spp-slice per rank + reduce(sum) to rank 0" if world > 1 else "single GPU",
+                       "sharding": ("%s shards per rank + reduce(sum) to rank 0" % args.shard) if world > 1 else "single GPU",
                        "kernel_path": "fast (wave-cooperative cells in LDS)" if fast else "generic (on-the-fly impulses)"},
             "roofline": {
                 "bound": "hbm", "kernel": kernel,

@@ -11,3 +11,4 @@ from .bindings import (  # noqa: F401
     PARAMS, MEAN, RAY_IN, SEG_OUT, COND_COEFF, QUERY, NEE_QUERY, DERIVED, SCENE_S,
     default_params, params_for_config, CTX, SCHEME, MEAN_TYPE,
 )
+from . import dist  # noqa: F401

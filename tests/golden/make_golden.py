@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""Regenerates the golden fixtures in this directory.  Run in the build container:
+
+    python tests/golden/make_golden.py
+
+Two kinds of vectors (the reference ships no tests, fixtures or scenes for this path — SURVEY.md §4):
+
+  ref_primitives.npz   produced by the REAL reference compiled in place (oracle/_ref: its own
+                       MathUtil.hpp / UniformSampler.hpp / TangentFrame.hpp / Gaussian.cpp):
+                       xxhash32 x4, PCG32 streams, the per-impulse draw order, Duff ONB, Box–Muller.
+  reference_kat.json   the outputs the reference's evaluator printed in this image.
+  oracle_*.npz         inputs + outputs of the oracle (CPU restatement) for every mode of the path.
+                       They pin the HIP path and guard the oracle against regressions; they are
+                       reference-derived only through the two files above ("parity unpinned"
+                       beyond them).
+"""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _gpis_pkg  # noqa: E402
+import oracle_bindings as ob  # noqa: E402
+from gpu_util import scene_rays, shadow_rays_from  # noqa: E402
+
+pkg = _gpis_pkg.load_package()
+f32 = np.float32
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def ref_primitives():
+    ref = ob.ref_lib()
+    assert ref is not None, "oracle/_ref must be built (needs /root/reference)"
+    rng = np.random.default_rng(20261004)
+    out = {}
+    for arity in (1, 2, 3, 4):
+        words = rng.integers(0, 2 ** 32, size=(512, arity), dtype=np.uint64).astype(np.uint32)
+        words[:4] = [[0] * arity, [1] * arity, [0xFFFFFFFF] * arity, list(range(1, arity + 1))]
+        fn = getattr(ref, "ref_xxhash32_%d" % arity)
+        out["hash%d_in" % arity] = words
+        out["hash%d_out" % arity] = np.array([fn(*[int(w) for w in row]) for row in words], dtype=np.uint32)
+    states = rng.integers(0, 2 ** 63, size=64, dtype=np.uint64)
+    states[:4] = [0, 1, 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF]
+    streams = np.zeros((64, 96), dtype=np.uint32)
+    draws = np.zeros((64, 4 * 16), dtype=f32)
+    normals = np.zeros((64, 8))
+    for i, s in enumerate(states):
+        ref.ref_pcg32_stream(ctypes.c_uint64(int(s)), 96, P(streams[i]))
+        ref.ref_cell3d_draws(ctypes.c_uint64(int(s)), 16, P(draws[i]))
+        ref.ref_sample_standard_normal2(ctypes.c_uint64(int(s)), 4, P(normals[i]))
+    out.update(pcg_state=states, pcg_stream=streams, cell3d_draws=draws, box_muller=normals)
+    ns = rng.standard_normal((128, 3)).astype(f32)
+    ns[:4] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0.3, -0.4, -0.0]]
+    frames = np.zeros((128, 9), dtype=f32)
+    for i, n in enumerate(ns):
+        ref.ref_tangent_frame(P(n), P(frames[i]))
+    out.update(frame_in=ns, frame_out=frames)
+    np.savez_compressed(os.path.join(HERE, "ref_primitives.npz"), **out)
+
+
+def queries(n, seed, spread=1.4):
+    rng = np.random.default_rng(seed)
+    q = np.zeros(n, dtype=pkg.QUERY)
+    q["p"] = rng.uniform(-spread, spread, (n, 3)).astype(f32)
+    d = rng.standard_normal((n, 3))
+    q["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+    q["t_segment"] = rng.uniform(0, 2, n).astype(f32)
+    q["info_t"] = rng.uniform(0, 3, n).astype(f32)
+    q["pixel"] = rng.integers(0, 1920, (n, 2))
+    q["spp"] = rng.integers(0, 64, n)
+    q["segment"] = rng.integers(0, 4, n)
+    q["scene_seed"] = 0xBA5EBA11
+    q["p"][0] = (0.9, 0.1, -0.2)
+    q["p"][1] = (-1.2, -0.3, -0.9)
+    q["p"][2] = (0.10606602, 0.21213204, -0.10606602)   # on cell faces of the world grid
+    return q
+
+
+CASES = {
+    # name: (config, overrides)
+    "C0_world": ("C0", {}),
+    "C1_isoray": ("C1", {}),
+    "C1_perpath_renewal_plus": ("C1", {"single_realization": 0, "correlation_context": pkg.CTX.RENEWAL_PLUS, "impulse_density": 12}),
+    "C0_perpath_renewal": ("C0", {"single_realization": 0, "correlation_context": pkg.CTX.RENEWAL}),
+    "C2_1d_mis": ("C2", {}),
+    "C3_multires": ("C3", {"impulse_density": 16, "correlation_context": pkg.CTX.RENEWAL_PLUS}),
+}
+
+
+def params_of(case):
+    cfg, over = CASES[case]
+    p = pkg.params_for_config(cfg)
+    for k, v in over.items():
+        p[k] = v
+    return p
+
+
+def oracle_vectors():
+    for case in CASES:
+        params = params_of(case)
+        orc = ob.Oracle(params, threads=8)
+        q = queries(192, 100 + len(case))
+        val, gid = orc.eval_value(q)
+        grad = orc.eval_gradient(q)
+        scene = ob.default_scene_s(96, 54, 1)
+        rays, us = scene_rays(ob, orc, scene, step=5)
+        seg, coeff = orc.sample_distance(rays, want_coeff=True)
+        sh = shadow_rays_from(ob, scene, rays, us, seg)
+        seg2, coeff2 = orc.sample_distance(sh, want_coeff=True)
+        vis = orc.transmittance(sh)
+        np.savez_compressed(os.path.join(HERE, "oracle_%s.npz" % case), params=params, q=q, value=val, gp_id=gid, grad=grad,
+                            rays=rays, seg=seg, coeff=coeff, shadow=sh, seg2=seg2, coeff2=coeff2, vis=vis)
+    # the C0 scene-S image: 64x64, 4 spp — radiance sums and per-pixel hit counts
+    orc = ob.Oracle(pkg.params_for_config("C0"), threads=8)
+    rad, hits = orc.render_scene_s(ob.default_scene_s(64, 64, 4), want_hits=True)
+    np.savez_compressed(os.path.join(HERE, "oracle_C0_image64.npz"), radiance_sum=rad, hits=hits)
+
+
+def reference_kat():
+    json.dump({
+        "source": "SURVEY.md 8c 'Observed output': the reference's own evaluator compiled and run in this image",
+        "config": "SE sigma=0.1 l=0.05 aniso=1, SphericalMean(0,1), ctx=none, seed=7, rho=8, single realization, world space, "
+                  "pixelSampleSegment=(3,4,0,0)",
+        "point": [0.9, 0.1, -0.2],
+        "evaluateValue_9g": "-0.00919273123",
+        "evaluateGradient_9g": ["-1.11124325", "1.23765218", "-2.80203676"],
+        "xxhash32_Vec4u_1_2_3_4": 2694834884,
+        "worldToLocal_diag_6g": "28.2843",
+    }, open(os.path.join(HERE, "reference_kat.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    ob.build()
+    ref_primitives()
+    reference_kat()
+    oracle_vectors()
+    print(sorted(os.listdir(HERE)))
