@@ -287,6 +287,10 @@ int gpis_sample_distance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays,
 int gpis_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible);
 int gpis_eval_value_host(gpis_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id);
 int gpis_eval_gradient_host(gpis_medium *m, size_t n, const gpis_query *q, float *grad3);
+int gpis_conditioning_host(gpis_medium *m, size_t n, const gpis_query *q, const float *target_val,
+                           const float *target_grad3, gpis_cond_coeff *coeff_out);
+int gpis_nee_pdf_host(gpis_medium *m, size_t n, const gpis_nee_query *q, float *pdf);
+int gpis_nee_grad_host(gpis_medium *m, size_t n, const gpis_nee_query *q, float *grad3);
 
 /* ---- measurement ---------------------------------------------------------------- */
 

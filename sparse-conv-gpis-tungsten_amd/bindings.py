@@ -194,6 +194,7 @@ class GpisLib:
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
         "gpis_xxhash32_batch", "gpis_pcg32_stream_batch",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
+        "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
         "gpis_default_scene_s", "gpis_render_scene_s",
     ]
@@ -228,6 +229,9 @@ class GpisLib:
         L.gpis_transmittance_host.argtypes = [vp, sz, vp, vp]
         L.gpis_eval_value_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_eval_gradient_host.argtypes = [vp, sz, vp, vp]
+        L.gpis_conditioning_host.argtypes = [vp, sz, vp, vp, vp, vp]
+        L.gpis_nee_pdf_host.argtypes = [vp, sz, vp, vp]
+        L.gpis_nee_grad_host.argtypes = [vp, sz, vp, vp]
         L.gpis_get_counters.argtypes = [vp, vp, vp]
         L.gpis_reset_counters.argtypes = [vp]
         L.gpis_set_profiling.argtypes = [vp, i32]

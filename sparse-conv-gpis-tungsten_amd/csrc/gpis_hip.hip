@@ -837,6 +837,53 @@ extern "C" int gpis_eval_gradient_host(gpis_medium *m, size_t n, const gpis_quer
     return GPIS_OK;
 }
 
+extern "C" int gpis_conditioning_host(gpis_medium *m, size_t n, const gpis_query *q, const float *target_val, const float *target_grad3,
+                                      gpis_cond_coeff *coeff_out)
+{
+    CHECK_ARGS(m && (n == 0 || (q && target_val && target_grad3 && coeff_out)));
+    if (n == 0) return GPIS_OK;
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    int st;
+    if ((st = ensure_stage(m, 0, n * sizeof(gpis_query))) || (st = ensure_stage(m, 1, 4 * n * sizeof(float))) ||
+        (st = ensure_stage(m, 2, n * sizeof(gpis_cond_coeff))))
+        return st;
+    float *d_tv = (float *)m->stage[1], *d_tg = d_tv + n;
+    HIP_TRY(hipMemcpy(m->stage[0], q, n * sizeof(gpis_query), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tv, target_val, n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tg, target_grad3, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+    st = gpis_conditioning_batch(m, n, (const gpis_query *)m->stage[0], d_tv, d_tg, (gpis_cond_coeff *)m->stage[2], nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(coeff_out, m->stage[2], n * sizeof(gpis_cond_coeff), hipMemcpyDeviceToHost));
+    return GPIS_OK;
+}
+static int nee_host(gpis_medium *m, size_t n, const gpis_nee_query *q, float *pdf, float *grad3)
+{
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    int st;
+    if ((st = ensure_stage(m, 0, n * sizeof(gpis_nee_query))) || (st = ensure_stage(m, 1, 3 * n * sizeof(float))))
+        return st;
+    HIP_TRY(hipMemcpy(m->stage[0], q, n * sizeof(gpis_nee_query), hipMemcpyHostToDevice));
+    st = pdf ? gpis_nee_pdf_batch(m, n, (const gpis_nee_query *)m->stage[0], (float *)m->stage[1], nullptr)
+             : gpis_nee_grad_batch(m, n, (const gpis_nee_query *)m->stage[0], (float *)m->stage[1], nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(pdf ? pdf : grad3, m->stage[1], (pdf ? 1 : 3) * n * sizeof(float), hipMemcpyDeviceToHost));
+    return GPIS_OK;
+}
+extern "C" int gpis_nee_pdf_host(gpis_medium *m, size_t n, const gpis_nee_query *q, float *pdf)
+{
+    CHECK_ARGS(m && (n == 0 || (q && pdf)));
+    return n ? nee_host(m, n, q, pdf, nullptr) : GPIS_OK;
+}
+extern "C" int gpis_nee_grad_host(gpis_medium *m, size_t n, const gpis_nee_query *q, float *grad3)
+{
+    CHECK_ARGS(m && (n == 0 || (q && grad3)));
+    return n ? nee_host(m, n, q, nullptr, grad3) : GPIS_OK;
+}
+
 // ---- measurement -------------------------------------------------------------------------
 extern "C" int gpis_get_counters(gpis_medium *m, uint64_t *n_eval, uint64_t *n_seg)
 {
