@@ -205,6 +205,13 @@ class GpisLib:
             raise RuntimeError(
                 "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
         self.path = path
+        # torch wheels bundle their own HIP runtime; when torch is going to be used in this process it
+        # has to initialise first so that this library binds to the same runtime instance
+        try:
+            import torch
+            torch.cuda.is_available()
+        except Exception:
+            pass
         self.lib = ctypes.CDLL(path)
         L = self.lib
         L.gpis_last_error.restype = ctypes.c_char_p

@@ -92,7 +92,7 @@ static void test_gpu()
         st.info.pixelSampleSegment[0] = 100 + i; st.info.pixelSampleSegment[1] = 50; st.info.pixelSampleSegment[2] = 3; st.info.pixelSampleSegment[3] = 0;
         st.info.sceneSeed = 0xBA5EBA11u;
         st.reset();
-        Vec3f d; d.x = -0.25f + 0.005f * i; d.y = 0.02f; d.z = -1.f;
+        Vec3f d; d.x = -0.5f + 0.0105f * i; d.y = 0.02f; d.z = -1.f;
         float len = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
         d.x /= len; d.y /= len; d.z /= len;
         Ray ray(o, d, 2.4f, 5.6f);
