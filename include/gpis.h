@@ -309,6 +309,24 @@ int gpis_set_profiling(gpis_medium *m, int enable);
 int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_t *launches,
                             uint64_t *n_eval, uint64_t *n_seg);
 
+/* ---- certified guide field (single-realization media) ------------------------ */
+
+/* Tabulates the medium's lattice noise on a grid of `points_per_cell` (8/16/32/64) samples per cell
+ * over |grid coordinate| < half_extent_cells, with a rigorous per-block error bound, and switches
+ * sampleDistance / transmittance to the guided march: steps whose sign the table certifies cost one
+ * lookup, all others run the exact evaluation, so results are unchanged.  Memory:
+ * (2*half*ppc)^3 * 4 bytes (4.3 GB for half=16, ppc=32).  Returns GPIS_ERR_UNSUPPORTED for media
+ * the wave-cooperative path does not cover.  gpis_drop_guide frees it. */
+int gpis_build_guide(gpis_medium *m, int half_extent_cells, int points_per_cell);
+int gpis_drop_guide(gpis_medium *m);
+/* Guide lookups performed since the last gpis_reset_counters (exact evaluations stay in n_eval). */
+int gpis_get_guide_steps(gpis_medium *m, uint64_t *n_guide);
+/* Test surface: evaluates the exact lattice sum and the guide at n grid-space points (device
+ * pointer, xyz triples; consecutive groups of 64 must lie within one cell of each other) and reports
+ * how many violate |exact - guide| <= bound (must be 0), the largest ratio and the mean bound. */
+int gpis_guide_selfcheck(gpis_medium *m, size_t n, const float *points3, uint64_t *checked,
+                         uint64_t *violations, float *max_ratio, float *mean_bound, void *stream);
+
 /* ---- tile → ray-batch driver (SURVEY.md §8d "Scene S", §8f-1) -------------------- */
 
 typedef struct gpis_scene_s {

@@ -196,6 +196,7 @@ class GpisLib:
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
+        "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck",
         "gpis_default_scene_s", "gpis_render_scene_s",
     ]
 
@@ -243,6 +244,10 @@ class GpisLib:
         L.gpis_reset_counters.argtypes = [vp]
         L.gpis_set_profiling.argtypes = [vp, i32]
         L.gpis_get_kernel_profile.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.gpis_build_guide.argtypes = [vp, i32, i32]
+        L.gpis_drop_guide.argtypes = [vp]
+        L.gpis_get_guide_steps.argtypes = [vp, vp]
+        L.gpis_guide_selfcheck.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
         L.gpis_default_scene_s.argtypes = [vp, u32, u32, u32]
         L.gpis_default_scene_s.restype = None
         L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
@@ -337,6 +342,24 @@ class Medium:
 
     def reset_counters(self):
         self.L.check(self.L.lib.gpis_reset_counters(self.h), "gpis_reset_counters")
+
+    def build_guide(self, half_extent_cells=16, points_per_cell=32):
+        self.L.check(self.L.lib.gpis_build_guide(self.h, int(half_extent_cells), int(points_per_cell)), "gpis_build_guide")
+
+    def drop_guide(self):
+        self.L.check(self.L.lib.gpis_drop_guide(self.h), "gpis_drop_guide")
+
+    def guide_steps(self):
+        n = ctypes.c_uint64()
+        self.L.check(self.L.lib.gpis_get_guide_steps(self.h, ctypes.byref(n)), "gpis_get_guide_steps")
+        return n.value
+
+    def guide_selfcheck(self, points3_dev_ptr, n, stream=None):
+        c, v = ctypes.c_uint64(), ctypes.c_uint64()
+        r, b = ctypes.c_float(), ctypes.c_float()
+        self.L.check(self.L.lib.gpis_guide_selfcheck(self.h, int(n), ctypes.c_void_p(int(points3_dev_ptr)), ctypes.byref(c), ctypes.byref(v),
+                                                     ctypes.byref(r), ctypes.byref(b), stream), "gpis_guide_selfcheck")
+        return c.value, v.value, r.value, b.value
 
     def set_profiling(self, on):
         self.L.check(self.L.lib.gpis_set_profiling(self.h, int(bool(on))), "gpis_set_profiling")

@@ -415,6 +415,70 @@ GPIS_DEV V3 coop_evaluate_gradient(const DevModel &M, const FastTable &T, FastLd
 
 enum Phase : int { PH_INIT = 0, PH_MARCH = 1, PH_REFINE = 2, PH_FINAL = 3, PH_GRAD = 4, PH_DONE = 5 };
 
+// The MediumSample / MediumState writes of GPM.cpp:224-340 for one finished segment.
+GPIS_DEV void finish_sample_distance(const DevModel &M, const gpis_ray_in *__restrict__ rayp, V3 pos, V3 dir, float farT, bool early_ok,
+                                     bool want_grad, bool hit, double t, float last_val, int gp, V3 g, gpis_seg_out *out)
+{
+    const float maxT = farT;
+    gpis_seg_out o;
+    o.t = 0.;
+    o.sample_t = 0.f; o.continued_t = 0.f;
+    for (int c = 0; c < 3; ++c) { o.weight[c] = 0.f; o.continued_weight[c] = 0.f; o.p[c] = 0.f; }
+    o.exited = 0; o.ok = 0; o.scheme = GPIS_UNI;
+    o.gp_id = rayp->last_gp_id;
+    o.last_val = rayp->last_val;
+    o.aniso[0] = rayp->last_aniso[0]; o.aniso[1] = rayp->last_aniso[1]; o.aniso[2] = rayp->last_aniso[2];
+    if (early_ok) {
+        o.weight[0] = o.weight[1] = o.weight[2] = 1.f;
+        o.exited = 1;
+        V3 pp = pos + dir * o.sample_t;
+        o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
+        o.ok = 1;
+        *out = o;
+        return;
+    }
+    if (!want_grad) {   // bounce limit
+        *out = o;
+        return;
+    }
+    V3d aniso = to_d(g);
+    o.t = t;
+    o.exited = hit ? 0 : 1;
+    o.last_val = last_val;
+    o.gp_id = gp;
+    bool ok = true;
+    if (hit) {
+        double avg = (aniso.x + aniso.y + aniso.z) / 3.0;
+        if (!__builtin_isfinite(avg)) {
+            aniso = V3d{1., 0., 0.};
+            ok = false;
+        } else {
+            double d = aniso.x * (double)dir.x; d += aniso.y * (double)dir.y; d += aniso.z * (double)dir.z;
+            double l2 = 0.; l2 += aniso.x * aniso.x; l2 += aniso.y * aniso.y; l2 += aniso.z * aniso.z;
+            if (d > 0) {
+                ok = false;
+            } else if (l2 < (double)0.0000001f) {
+                aniso = V3d{1., 0., 0.};
+                ok = false;
+            }
+        }
+    }
+    o.aniso[0] = aniso.x; o.aniso[1] = aniso.y; o.aniso[2] = aniso.z;
+    if (ok) {
+        float ft = (float)t;
+        o.sample_t = ft < maxT ? ft : maxT;
+        o.continued_t = ft;
+        for (int c = 0; c < 3; ++c) {
+            o.weight[c] = 1.f * M.sigma_s_over_t[c];
+            o.continued_weight[c] = 1.f * M.sigma_s_over_t[c];
+        }
+        V3 pp = pos + dir * o.sample_t;
+        o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
+        o.ok = 1;
+    }
+    *out = o;
+}
+
 // The march of one wave of segments.  WANT_SAMPLE: sampleDistance (GPM.cpp:221-341) — otherwise
 // transmittance (GPM.cpp:343-393), whose result does not depend on the end-of-segment gradient nor
 // on lastVal, so those two evaluations are not performed.
@@ -546,64 +610,7 @@ GPIS_DEV void fast_march(const DevModel &M, const FastTable &T, FastLds &lds, bo
     if (!valid)
         return;
 
-    const float maxT = farT;
-    gpis_seg_out o;
-    o.t = 0.;
-    o.sample_t = 0.f; o.continued_t = 0.f;
-    for (int c = 0; c < 3; ++c) { o.weight[c] = 0.f; o.continued_weight[c] = 0.f; o.p[c] = 0.f; }
-    o.exited = 0; o.ok = 0; o.scheme = GPIS_UNI;
-    o.gp_id = rayp->last_gp_id;
-    o.last_val = rayp->last_val;
-    o.aniso[0] = rayp->last_aniso[0]; o.aniso[1] = rayp->last_aniso[1]; o.aniso[2] = rayp->last_aniso[2];
-    if (early_ok) {
-        o.weight[0] = o.weight[1] = o.weight[2] = 1.f;
-        o.exited = 1;
-        V3 pp = pos + dir * o.sample_t;
-        o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
-        o.ok = 1;
-        *out = o;
-        return;
-    }
-    if (!want_grad) {   // bounce limit
-        *out = o;
-        return;
-    }
-    V3d aniso = to_d(g);
-    o.t = t;
-    o.exited = hit ? 0 : 1;
-    o.last_val = last_val;
-    o.gp_id = gp;
-    bool ok = true;
-    if (hit) {
-        double avg = (aniso.x + aniso.y + aniso.z) / 3.0;
-        if (!__builtin_isfinite(avg)) {
-            aniso = V3d{1., 0., 0.};
-            ok = false;
-        } else {
-            double d = aniso.x * (double)dir.x; d += aniso.y * (double)dir.y; d += aniso.z * (double)dir.z;
-            double l2 = 0.; l2 += aniso.x * aniso.x; l2 += aniso.y * aniso.y; l2 += aniso.z * aniso.z;
-            if (d > 0) {
-                ok = false;
-            } else if (l2 < (double)0.0000001f) {
-                aniso = V3d{1., 0., 0.};
-                ok = false;
-            }
-        }
-    }
-    o.aniso[0] = aniso.x; o.aniso[1] = aniso.y; o.aniso[2] = aniso.z;
-    if (ok) {
-        float ft = (float)t;
-        o.sample_t = ft < maxT ? ft : maxT;
-        o.continued_t = ft;
-        for (int c = 0; c < 3; ++c) {
-            o.weight[c] = 1.f * M.sigma_s_over_t[c];
-            o.continued_weight[c] = 1.f * M.sigma_s_over_t[c];
-        }
-        V3 pp = pos + dir * o.sample_t;
-        o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
-        o.ok = 1;
-    }
-    *out = o;
+    finish_sample_distance(M, rayp, pos, dir, farT, early_ok, want_grad, hit, t, last_val, gp, g, out);
 }
 
 __device__ __forceinline__ void fast_flush_counters(Counters *cnt, uint32_t n_eval, uint32_t n_seg)

@@ -1,0 +1,544 @@
+// gpis_guide.hpp — certified guide field for single-realization media (this is what the 288 GB
+// of HBM are for).
+//
+// With single_realization the noise3D sum (SCN.cpp:362-395) is ONE fixed function N(u) of the
+// grid-space position u = p_grid (cell units), the same for every ray.  The march (SCNM.cpp:132-174)
+// only needs the SIGN of sigma*N/norm + mean at almost every step; the value matters at the crossing
+// step, the step before it, during refinement and at the segment end.  So:
+//
+//   G   = trilinear interpolation of samples of the SMOOTH sum S(u) = sum_i w_i exp(-q_i(u)) over all
+//         impulses (no unit-ball cut-off), q_i = sum_a alpha_a delta_a^2, delta = u - (cell + p_i),
+//         alpha_a = A_a R^2, on a grid of spacing h = 1/ppc cells,
+//   Err = a RIGOROUS bound on |N_ref(u) - G(u)| for every u of a 4x4x4-point block, stored per block.
+//
+// A march step whose |sigma*G/norm + mean| exceeds sigma*Err/norm (+ rounding slack) has a certified
+// sign and costs one 8-tap lookup instead of 27*rho kernel evaluations; all other steps run the exact
+// cooperative evaluation, so every output is bit-identical to the exact path.
+//
+// Error budget for u in the cell anchored at grid point g (m = h*sqrt(3) = the cell diagonal), all
+// sums over impulses i, every term an upper bound valid on the whole cell:
+//   truncation  T = sum_{|delta_i(g)| >= 1-1e-5-m} exp(-amin * max(1-1e-5, |delta_i(g)|-m)^2)
+//                 (the reference drops impulse i when its fp32 |delta|^2 < 1 test fails; whatever it
+//                  drops has |delta| >= 1-1e-5 and contributes at most this much)
+//   interpolation E = (h^2/8) * sum_a sum_i max(4 alpha_a^2 (|delta_a(g)|+h)^2 - 2 alpha_a, 2 alpha_a)
+//                                          * exp(-amin * max(|delta_i(g)|-m, 0)^2)
+//                 (multilinear interpolation error <= sum_a h^2/8 sup|d_aa S|, and
+//                  d_aa exp(-q) = (4 alpha_a^2 delta_a^2 - 2 alpha_a) exp(-q))
+//   culled      impulses farther than r_c from the block are skipped: n_culled * exp(-amin r_c^2)
+//                 (+ their share of E), cells beyond the 5x5x5 block: 218 * n * exp(-4 amin)
+//   rounding    fp32 accumulation of <= ~700 terms, v_exp_f32, the lerp: 5e-4 absolute
+// amin = min_a alpha_a.  Bounds are accumulated in fp32 and inflated by 1e-3 relative.
+#pragma once
+#include "gpis_fast.hpp"
+
+#pragma clang fp contract(off)
+
+namespace gpis {
+
+struct GuideField {
+    float *G;            // side^3 samples, z fastest
+    float *err;          // (side/4)^3 block bounds
+    int half;            // extent in cells: u in [-half, half)
+    int ppc;             // grid points per cell (h = 1/ppc)
+    int side;            // 2*half*ppc
+    float alpha[3];      // A_a * R^2
+    float R;             // kernelRadius of the grid space
+    int enabled;
+};
+
+constexpr float kGuideCullRadius = 1.75f;
+
+// one wave = one 4x4x4 block of grid points
+__global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t block_offset)
+{
+    const DevModel &M = *Mp;
+    const int lane = (int)(threadIdx.x & 63);
+    const int bs = F.side / 4;
+    const size_t b = block_offset + blockIdx.x;
+    const int bz = (int)(b % bs), by = (int)((b / bs) % bs), bx = (int)(b / ((size_t)bs * bs));
+    const int lz = lane & 3, ly = (lane >> 2) & 3, lx = lane >> 4;
+    const int ix = 4 * bx + lx, iy = 4 * by + ly, iz = 4 * bz + lz;
+    const float h = 1.0f / (float)F.ppc;
+    // grid point in cell units; exact in fp32 (multiples of 1/32 below 2^5)
+    const float ux = (float)ix * h - (float)F.half, uy = (float)iy * h - (float)F.half, uz = (float)iz * h - (float)F.half;
+    // the block's box [lo, lo+3h] expanded by h (the cells anchored at its points)
+    const float lox = (float)(4 * bx) * h - (float)F.half, loy = (float)(4 * by) * h - (float)F.half, loz = (float)(4 * bz) * h - (float)F.half;
+    const int c0x = (int)floorf(lox), c0y = (int)floorf(loy), c0z = (int)floorf(loz);   // same lattice cell for the whole block
+    const float ax = F.alpha[0], ay = F.alpha[1], az = F.alpha[2];
+    const float amin = fminf(ax, fminf(ay, az)), amax = fmaxf(ax, fmaxf(ay, az));
+    const float m = h * 1.7320509f;
+    const uint32_t n = M.n_impulses;
+    const int H = T.half, S = T.stride;
+    const unsigned tside = 2u * (unsigned)H;
+    float Ssum = 0.f, Tsum = 0.f, Esum = 0.f;
+    uint32_t n_culled = 0;
+    for (int dx = -2; dx <= 2; ++dx)
+        for (int dy = -2; dy <= 2; ++dy)
+            for (int dz = -2; dz <= 2; ++dz) {
+                const int cx = c0x + dx, cy = c0y + dy, cz = c0z + dz;
+                float px, py, pz, pw;
+                if (T.cells && (unsigned)(cx + H) < tside && (unsigned)(cy + H) < tside && (unsigned)(cz + H) < tside) {
+                    const size_t idx = (((size_t)(cx + H) * tside + (size_t)(cy + H)) * tside + (size_t)(cz + H)) * (size_t)S;
+                    const float4 v = T.cells[idx + (size_t)(lane & (S - 1))];
+                    px = v.x; py = v.y; pz = v.z; pw = v.w;
+                } else {
+                    gen_impulse((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, M.seed, kJump4.A[lane], kJump4.C[lane], px, py, pz, pw);
+                }
+                // impulse position relative to the block's low corner, distance to the expanded box
+                const float rx = (float)cx + px - lox, ry = (float)cy + py - loy, rz = (float)cz + pz - loz;
+                const float gx = fmaxf(fmaxf(-rx, rx - 4.f * h), 0.f), gy = fmaxf(fmaxf(-ry, ry - 4.f * h), 0.f), gz = fmaxf(fmaxf(-rz, rz - 4.f * h), 0.f);
+                const bool valid_k = (uint32_t)lane < n;
+                const bool near_k = valid_k && (gx * gx + gy * gy + gz * gz) < (kGuideCullRadius + 1e-3f) * (kGuideCullRadius + 1e-3f);
+                unsigned long long cand = __ballot(near_k);
+                n_culled += (uint32_t)__popcll(__ballot(valid_k && !near_k));
+                while (cand) {
+                    const int k = __builtin_ctzll(cand);
+                    cand &= cand - 1ULL;
+                    const float iw = lane_f(pw, k);
+                    // delta = u - (cell + p_i)
+                    const float ddx = ux - ((float)cx + lane_f(px, k)), ddy = uy - ((float)cy + lane_f(py, k)), ddz = uz - ((float)cz + lane_f(pz, k));
+                    const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                    const float q = ax * ddx * ddx + ay * ddy * ddy + az * ddz * ddz;
+                    Ssum += iw * __expf(-q);
+                    const float dn = sqrtf(d2);
+                    const float dm = fmaxf(dn - m, 0.f);
+                    const float e_dm = __expf(-amin * dm * dm);
+                    const float adx = fabsf(ddx) + h, ady = fabsf(ddy) + h, adz = fabsf(ddz) + h;
+                    const float cxx = fmaxf(4.f * ax * ax * adx * adx - 2.f * ax, 2.f * ax);
+                    const float cyy = fmaxf(4.f * ay * ay * ady * ady - 2.f * ay, 2.f * ay);
+                    const float czz = fmaxf(4.f * az * az * adz * adz - 2.f * az, 2.f * az);
+                    Esum += (cxx + cyy + czz) * e_dm;
+                    if (dn >= 1.f - 1e-5f - m) {
+                        const float dt = fmaxf(1.f - 1e-5f, dn - m);
+                        Tsum += __expf(-amin * dt * dt);
+                    }
+                }
+            }
+    const float e_cull = __expf(-amin * kGuideCullRadius * kGuideCullRadius);
+    const float far_cells = 218.f * (float)n * __expf(-4.f * amin);
+    float err = (h * h * 0.125f) * (Esum + (float)n_culled * 3.f * (4.f * amax * amax * 9.f) * e_cull) + Tsum + (float)n_culled * e_cull + far_cells;
+    err = err * 1.001f + 5e-4f;
+    F.G[((size_t)ix * F.side + (size_t)iy) * F.side + (size_t)iz] = Ssum;
+    float emax = err;
+    for (int off = 32; off > 0; off >>= 1) emax = fmaxf(emax, __shfl_xor(emax, off, 64));
+    if (lane == 0)
+        F.err[((size_t)bx * bs + (size_t)by) * bs + (size_t)bz] = emax;
+}
+
+// G(u) and the bound for the cell containing u; false when u is outside the tabulated volume
+GPIS_DEV bool guide_lookup(const GuideField &F, V3 u, float &g, float &err)
+{
+    const float s = (float)F.ppc, off = (float)F.half;
+    const float tx = (u.x + off) * s, ty = (u.y + off) * s, tz = (u.z + off) * s;
+    const float fx0 = floorf(tx), fy0 = floorf(ty), fz0 = floorf(tz);
+    const float lim = (float)(F.side - 2);
+    if (!(fx0 >= 0.f && fy0 >= 0.f && fz0 >= 0.f && fx0 <= lim && fy0 <= lim && fz0 <= lim))
+        return false;
+    const int ix = (int)fx0, iy = (int)fy0, iz = (int)fz0;
+    const float wx = tx - fx0, wy = ty - fy0, wz = tz - fz0;
+    const size_t side = (size_t)F.side;
+    const float *p00 = F.G + ((size_t)ix * side + (size_t)iy) * side + (size_t)iz;
+    const float *p01 = p00 + side, *p10 = p00 + side * side, *p11 = p10 + side;
+    const float a000 = p00[0], a001 = p00[1], a010 = p01[0], a011 = p01[1];
+    const float a100 = p10[0], a101 = p10[1], a110 = p11[0], a111 = p11[1];
+    const float c00 = a000 + (a001 - a000) * wz, c01 = a010 + (a011 - a010) * wz;
+    const float c10 = a100 + (a101 - a100) * wz, c11 = a110 + (a111 - a110) * wz;
+    const float c0 = c00 + (c01 - c00) * wy, c1 = c10 + (c11 - c10) * wy;
+    g = c0 + (c1 - c0) * wx;
+    const size_t bs = side / 4;
+    err = F.err[((size_t)(ix >> 2) * bs + (size_t)(iy >> 2)) * bs + (size_t)(iz >> 2)];
+    return true;
+}
+
+// fp32 mean for the certification (the exact path evaluates it in double, GPF.hpp:903-945);
+// `slack` returns a bound on its absolute error
+GPIS_DEV float mean_approx(const DevModel &M, V3 p, float &slack)
+{
+    float best = 0.f;
+    slack = 0.f;
+    for (int w = 0; w < (M.has_mean_additional ? 2 : 1); ++w) {
+        const gpis_mean &mu = M.mean[w];
+        float v, s;
+        if (mu.type == GPIS_MEAN_HOMOGENEOUS) {
+            v = mu.offset; s = 0.f;
+        } else if (mu.type == GPIS_MEAN_SPHERICAL) {
+            const float dx = p.x - (float)mu.center[0], dy = p.y - (float)mu.center[1], dz = p.z - (float)mu.center[2];
+            const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+            v = r - mu.radius;
+            s = 4e-7f * (r + fabsf((float)mu.center[0]) + fabsf((float)mu.center[1]) + fabsf((float)mu.center[2]) + fabsf(mu.radius)) + 1e-7f;
+        } else {
+            const float dx = p.x - (float)mu.center[0], dy = p.y - (float)mu.center[1], dz = p.z - (float)mu.center[2];
+            const float d = dx * (float)M.lin_dir[w][0] + dy * (float)M.lin_dir[w][1] + dz * (float)M.lin_dir[w][2];
+            v = fmaxf(d * mu.scale, mu.min);
+            s = 1e-6f * (fabsf(d * mu.scale) + fabsf(mu.scale) * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + 1.f)) + 1e-7f;
+        }
+        if (w == 0 || v < best) best = v;          // CSG min (GaussianProcess.cpp:379-393): |min(a,b) - min(a',b')| <= max err
+        slack = fmaxf(slack, s);
+    }
+    return best;
+}
+
+// ---- the guided march -------------------------------------------------------------------------
+// Per lane (SCNM.cpp:102-183 restated around the certification):
+//   G_INIT    sign0 = sign(f(nearT)) from the guide, else X_F0 (exact)
+//   G_MARCH   one guide step per iteration: a certified step with the expected sign just advances;
+//             anything else (uncertain, or a certified sign change) parks the lane for an exact
+//             evaluation at t (X_CUR) and — when a crossing is confirmed while the previous step's
+//             value is only known by sign — at the previous position (X_PREV), before the reference's
+//             secant-and-shrink refinement (X_REFINE) runs on exact values only
+//   X_FINAL   exact lastVal at farT (sampleDistance only), G_GRAD exact gradient, G_DONE
+// Exact evaluations are cooperative (coop_evaluate_value); parked lanes are served in clusters whose
+// grid cells span at most 2 per axis, so the evaluator always takes its coherent path.
+enum GPhase : int { G_INIT = 0, G_MARCH = 1, X_F0 = 2, X_CUR = 3, X_PREV = 4, X_REFINE = 5, X_FINAL = 6, G_GRAD = 7, G_DONE = 8 };
+
+GPIS_DEV V3 grid_point(const DevModel &M, const GuideField &F, V3 p, const Frame &coord)
+{
+    if (!M.iso3d)
+        return p / F.R;
+    return to_local(coord, cov_pos_w2l(M, p, 1.0f)) / F.R;
+}
+
+// certified sign of the field at world point p: +1 / -1, or 0 when the guide cannot decide
+GPIS_DEV int guide_sign(const DevModel &M, const GuideField &F, V3 p, const Frame &coord)
+{
+    float g, err;
+    if (!guide_lookup(F, grid_point(M, F, p, coord), g, err))
+        return 0;
+    const float norm = M.iso3d ? M.norm3d_iso : M.norm3d_world;
+    float ms;
+    const float mean = mean_approx(M, p, ms);
+    const float nv = M.sigma * (g / norm);
+    const float fa = nv + mean;
+    const float margin = M.sigma * (err / norm) * 1.0001f + ms + 2e-6f * (fabsf(nv) + fabsf(mean)) + 1e-7f;
+    if (fa > margin) return 1;
+    if (fa < -margin) return -1;
+    return 0;
+}
+
+template <bool WANT_SAMPLE>
+GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideField &F, FastLds &lds, bool valid,
+                           const gpis_ray_in *__restrict__ rayp, gpis_seg_out *out, bool &visible, uint32_t &n_eval, uint32_t &n_guide)
+{
+    V3 pos = v3(0.f, 0.f, 1.f), dir = v3(0.f, 0.f, 1.f);
+    float nearT = 0.f, farT = 1.f, u_jitter = 0.f;
+    bool first_scatter = true;
+    int bounce = 0;
+    if (valid) {
+        pos = v3(rayp->pos[0], rayp->pos[1], rayp->pos[2]);
+        dir = v3(rayp->dir[0], rayp->dir[1], rayp->dir[2]);
+        nearT = rayp->near_t; farT = rayp->far_t; u_jitter = rayp->u_jitter;
+        first_scatter = rayp->first_scatter != 0;
+        bounce = rayp->bounce;
+    }
+    if (!__builtin_isfinite(farT))
+        farT = (float)((double)nearT + 2000);
+    float step_size = (farT - nearT) / (float)M.min_step;
+    if (M.step_size < step_size)
+        step_size = M.step_size;
+    Frame coord{};
+    if (M.iso3d)
+        coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
+
+    int phase = G_INIT;
+    bool early_ok = false;
+    if (!valid)
+        phase = G_DONE;
+    else if (WANT_SAMPLE && bounce >= M.max_bounces)
+        phase = G_DONE;
+    else if (WANT_SAMPLE && farT == 0.f) {
+        phase = G_DONE;
+        early_ok = true;
+    }
+    double t = (double)nearT;          // position of the march step being decided
+    double t_prevpos = (double)nearT;  // position the previous value `pf` belongs to
+    double a_lo = 0., intp = 0., t_test = 0., t_prev = 0.;
+    float pf = 0.f, fc = 0.f;
+    bool pf_valid = false;             // pf is an exact value (otherwise only its sign is known)
+    int sign0 = 1, step = 0, gp = 0;
+    float last_val = 0.f;
+    bool hit = false;
+
+    auto world_at = [&](double tq) { return to_f(ray_at(to_d(pos), to_d(dir), tq)); };
+    // after the evaluation at nearT: t = nearT + step*u (float arithmetic, SCNM.cpp:129)
+    auto begin_march = [&]() {
+        t_prevpos = (double)nearT;
+        t = (double)(nearT + step_size * u_jitter);
+        phase = (t < (double)farT) ? G_MARCH : X_FINAL;
+    };
+    auto advance = [&]() {
+        t_prevpos = t;
+        t += (double)step_size;
+        phase = (t < (double)farT) ? G_MARCH : X_FINAL;
+    };
+    auto begin_refine = [&]() {   // SCNM.cpp:143-146
+        intp = (double)pf / ((double)pf - (double)fc);
+        a_lo = t - (double)step_size;
+        t_prev = lerp_d(a_lo, t, intp);
+        t_test = t_prev;
+        phase = X_REFINE;
+    };
+
+    for (;;) {
+        // ---- A: guide steps for every lane that can take one ----
+        for (;;) {
+            if (!WANT_SAMPLE && phase == X_FINAL) {
+                hit = false;                // transmittance: the segment exits, lastVal is not part of the result
+                phase = G_DONE;
+            }
+            const bool stepping = phase == G_INIT || phase == G_MARCH;
+            if (__ballot(stepping) == 0ULL)
+                break;
+            if (stepping) {
+                n_guide++;
+                if (phase == G_INIT) {
+                    const int s = guide_sign(M, F, world_at((double)nearT), coord);
+                    if (s != 0) {
+                        sign0 = s;
+                        pf_valid = false;
+                        begin_march();
+                    } else {
+                        phase = X_F0;
+                    }
+                } else {
+                    const int s = guide_sign(M, F, world_at(t), coord);
+                    const bool adopt = !first_scatter && step == 0;   // the reference's `step == 1` after step++ (SCNM.cpp:138-140)
+                    if (s != 0 && (adopt || s == sign0)) {
+                        step++;
+                        if (adopt) sign0 = s;
+                        pf_valid = false;
+                        advance();
+                    } else {
+                        phase = X_CUR;      // uncertain, or a certified sign change: exact values needed
+                    }
+                }
+            }
+        }
+        // ---- B: exact evaluations for the parked lanes, one coherent cluster at a time ----
+        const bool need = phase >= X_F0 && phase <= X_FINAL;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask == 0ULL)
+            break;
+        const double tq = phase == X_F0 ? (double)nearT : (phase == X_PREV ? t_prevpos : (phase == X_REFINE ? t_test : (phase == X_FINAL ? (double)farT : t)));
+        const V3 pq = world_at(tq);
+        const V3 ug = grid_point(M, F, pq, coord);
+        const int cx = (int)floorf(ug.x), cy = (int)floorf(ug.y), cz = (int)floorf(ug.z);
+        const int lead = __builtin_ctzll(need_mask);
+        const int ax0 = __builtin_amdgcn_readlane(cx, lead), ay0 = __builtin_amdgcn_readlane(cy, lead), az0 = __builtin_amdgcn_readlane(cz, lead);
+        // the lead lane is always in its own cluster, so every round retires at least one request
+        const bool in_cluster = need && cx >= ax0 && cx <= ax0 + 1 && cy >= ay0 && cy <= ay0 + 1 && cz >= az0 && cz <= az0 + 1;
+        int gp_new;
+        const float fv = coop_evaluate_value(M, T, lds, in_cluster, pq, coord, gp_new, n_eval);
+        if (in_cluster) {
+            gp = gp_new;
+            const double f = (double)fv;
+            if (phase == X_F0) {                       // SCNM.cpp:125-128
+                sign0 = f < 0 ? -1 : 1;
+                pf = fv;
+                pf_valid = true;
+                begin_march();
+            } else if (phase == X_CUR) {               // SCNM.cpp:133-141, 172-173
+                step++;
+                const int signc = f < 0 ? -1 : 1;
+                if (!first_scatter && step == 1) {
+                    sign0 = signc;
+                    pf = fv; pf_valid = true;
+                    advance();
+                } else if (signc != sign0) {
+                    fc = fv;
+                    if (pf_valid) begin_refine();
+                    else phase = X_PREV;
+                } else {
+                    pf = fv; pf_valid = true;
+                    advance();
+                }
+            } else if (phase == X_PREV) {
+                pf = fv; pf_valid = true;
+                begin_refine();
+            } else if (phase == X_REFINE) {            // SCNM.cpp:147-160
+                const int sign_test = f < 0 ? -1 : 1;
+                bool done = false;
+                if (sign_test == sign0) {
+                    done = true;
+                } else {
+                    intp *= 0.9;
+                    if (intp <= 0.01) {
+                        t_prev = t_test = 0;
+                        done = true;
+                    } else {
+                        t_prev = t_test;
+                        t_test = lerp_d(a_lo, t, intp);
+                    }
+                }
+                if (done) {
+                    t = t_prev;
+                    hit = true;
+                    last_val = 0.0f;
+                    phase = WANT_SAMPLE ? G_GRAD : G_DONE;
+                }
+            } else {                                   // X_FINAL: lastVal at farT (SCNM.cpp:176-181)
+                t = (double)farT;
+                last_val = fv;
+                hit = false;
+                phase = G_GRAD;
+            }
+        }
+    }
+    visible = valid && !hit;
+    if (!WANT_SAMPLE)
+        return;
+
+    // one gradient evaluation per segment (GPM.cpp:283 / 319), clustered like the value requests
+    const bool want_grad = phase == G_GRAD;
+    V3 g = v3(0.f, 0.f, 0.f);
+    {
+        V3d rdn = to_d(dir);
+        { double inv = 1.0 / length_d(rdn); rdn.x *= inv; rdn.y *= inv; rdn.z *= inv; }
+        const V3 pgq = to_f(ray_at(to_d(pos), rdn, t));
+        const V3 ug = grid_point(M, F, pgq, coord);
+        const int cx = (int)floorf(ug.x), cy = (int)floorf(ug.y), cz = (int)floorf(ug.z);
+        bool pending = want_grad;
+        for (;;) {
+            const unsigned long long pm = __ballot(pending);
+            if (pm == 0ULL)
+                break;
+            const int lead = __builtin_ctzll(pm);
+            const int ax0 = __builtin_amdgcn_readlane(cx, lead), ay0 = __builtin_amdgcn_readlane(cy, lead), az0 = __builtin_amdgcn_readlane(cz, lead);
+            const bool in_cluster = pending && cx >= ax0 && cx <= ax0 + 1 && cy >= ay0 && cy <= ay0 + 1 && cz >= az0 && cz <= az0 + 1;
+            const V3 gi = coop_evaluate_gradient(M, T, lds, in_cluster, pgq, coord, n_eval);
+            if (in_cluster) {
+                g = gi;
+                pending = false;
+            }
+        }
+    }
+    if (!valid)
+        return;
+    finish_sample_distance(M, rayp, pos, dir, farT, early_ok, want_grad, hit, t, last_val, gp, g, out);
+}
+
+struct GuideCounters { unsigned long long n_guide; };
+
+__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_guided_sample_distance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+                                                                                     const gpis_ray_in *__restrict__ rays, gpis_seg_out *__restrict__ out,
+                                                                                     gpis_cond_coeff *__restrict__ coeff, const uint8_t *__restrict__ mask,
+                                                                                     Counters *cnt, unsigned long long *guide_cnt)
+{
+    __shared__ FastLds lds;
+    fast_lds_init(lds);
+    size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
+    const bool valid = i < n && (!mask || mask[i]);
+    uint32_t n_eval = 0, n_guide = 0;
+    bool vis;
+    guided_march<true>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval, n_guide);
+    if (valid && coeff) {
+        gpis_cond_coeff c;
+        memset(&c, 0, sizeof c);
+        c.n_evals = n_eval;
+        coeff[i] = c;
+    }
+    fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
+    unsigned long long gsum = n_guide;
+    for (int off = 32; off > 0; off >>= 1) gsum += __shfl_down(gsum, off, 64);
+    if ((threadIdx.x & 63) == 0 && gsum) atomicAdd(guide_cnt, gsum);
+}
+
+__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+                                                                                   const gpis_ray_in *__restrict__ rays, uint8_t *__restrict__ visible,
+                                                                                   const uint8_t *__restrict__ mask, Counters *cnt, unsigned long long *guide_cnt)
+{
+    __shared__ FastLds lds;
+    fast_lds_init(lds);
+    size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
+    const bool valid = i < n && (!mask || mask[i]);
+    uint32_t n_eval = 0, n_guide = 0;
+    bool vis = false;
+    guided_march<false>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), nullptr, vis, n_eval, n_guide);
+    if (i < n)
+        visible[i] = (valid && vis) ? 1 : 0;
+    fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
+    unsigned long long gsum = n_guide;
+    for (int off = 32; off > 0; off >>= 1) gsum += __shfl_down(gsum, off, 64);
+    if ((threadIdx.x & 63) == 0 && gsum) atomicAdd(guide_cnt, gsum);
+}
+
+// Self-check (test surface): for n query points — taken in coherent groups of 64 — evaluates the exact
+// noise3D sum and the guide, and counts violations of |N_ref - G| <= Err.  stats[0] = points checked,
+// stats[1] = violations, stats[2] = bits of max(|N_ref - G| / Err), stats[3] = bits of the mean Err.
+__global__ void __launch_bounds__(kFastBlock) k_guide_selfcheck(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+                                                               const float *__restrict__ points3, unsigned long long *stats, float *ratio_max, float *err_sum)
+{
+    __shared__ FastLds lds;
+    fast_lds_init(lds);
+    const DevModel &M = *Mp;
+    size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
+    const bool valid = i < n;
+    V3 u = v3(0.f, 0.f, 0.f);
+    if (valid) u = v3(points3[3 * i], points3[3 * i + 1], points3[3 * i + 2]);
+    // u is given in grid space already: evaluate the exact sum there
+    float A0, A1, A2;
+    if (!M.iso3d) { A0 = M.invcov_world[0] * 0.5f; A1 = M.invcov_world[4] * 0.5f; A2 = M.invcov_world[8] * 0.5f; }
+    else { A0 = A1 = A2 = 0.5f; }
+    const V3 p = F.R * u;
+    const V4 ex = coop_noise3d<false>(M, T, lds, valid, p, M.seed, F.R, A0, A1, A2);
+    float g, err;
+    const V3 pg = p / F.R;   // the grid point the exact evaluator used
+    const bool ok = valid && guide_lookup(F, pg, g, err);
+    float ratio = 0.f;
+    unsigned long long bad = 0, cnt = 0;
+    float es = 0.f;
+    if (ok) {
+        ratio = fabsf(ex.v - g) / err;
+        bad = ratio > 1.0f ? 1 : 0;
+        cnt = 1;
+        es = err;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_down(bad, off, 64);
+        cnt += __shfl_down(cnt, off, 64);
+        ratio = fmaxf(ratio, __shfl_down(ratio, off, 64));
+        es += __shfl_down(es, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[0], cnt);
+        atomicAdd(&stats[1], bad);
+        atomicMax((unsigned int *)ratio_max, __float_as_uint(ratio));   // non-negative floats order like their bits
+        atomicAdd(err_sum, es);
+    }
+}
+
+inline void guide_free(GuideField *F)
+{
+    if (F->G) (void)hipFree(F->G);
+    if (F->err) (void)hipFree(F->err);
+    F->G = nullptr; F->err = nullptr; F->enabled = 0;
+}
+
+// Builds the guide field for the grid space of medium M (world space or isotropic-ray space).
+inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTable &T, int half, int ppc, GuideField *F)
+{
+    guide_free(F);
+    if (!fast_supported(M) || half < 2 || half > 64 || (ppc != 8 && ppc != 16 && ppc != 32 && ppc != 64))
+        return GPIS_ERR_UNSUPPORTED;
+    F->half = half; F->ppc = ppc; F->side = 2 * half * ppc;
+    if (!M.iso3d) {
+        F->R = M.radius_world;
+        for (int a = 0; a < 3; ++a) F->alpha[a] = (M.invcov_world[4 * a] * 0.5f) * F->R * F->R;
+    } else {
+        F->R = M.radius_iso;
+        for (int a = 0; a < 3; ++a) F->alpha[a] = 0.5f * F->R * F->R;
+    }
+    const size_t npts = (size_t)F->side * F->side * F->side;
+    const size_t nblk = npts / 64;
+    if (hipMalloc(&F->G, npts * sizeof(float)) != hipSuccess) { F->G = nullptr; (void)hipGetLastError(); return GPIS_ERR_DEVICE; }
+    if (hipMalloc(&F->err, nblk * sizeof(float)) != hipSuccess) { F->err = nullptr; guide_free(F); (void)hipGetLastError(); return GPIS_ERR_DEVICE; }
+    const size_t per_launch = (size_t)1 << 22;   // slabs of 4 Mi blocks
+    for (size_t b0 = 0; b0 < nblk; b0 += per_launch) {
+        const size_t nb = nblk - b0 < per_launch ? nblk - b0 : per_launch;
+        k_guide_build<<<(unsigned)nb, 64>>>(d_model, T, *F, b0);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { guide_free(F); return GPIS_ERR_DEVICE; }
+    F->enabled = 1;
+    return GPIS_OK;
+}
+
+}   // namespace gpis

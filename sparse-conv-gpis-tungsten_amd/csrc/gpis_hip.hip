@@ -23,6 +23,7 @@
 #include "gpis.h"
 #include "gpis_device.hpp"
 #include "gpis_fast.hpp"
+#include "gpis_guide.hpp"
 
 #pragma clang fp contract(off)
 
@@ -67,6 +68,8 @@ struct gpis_medium {
     DevModel *d_model;
     Counters *d_counters;
     FastTable fast;          // single-realization wave-cooperative path (gpis_fast.hpp); enabled == 0 when unused
+    GuideField guide;        // certified guide field (gpis_guide.hpp); enabled == 0 until gpis_build_guide
+    unsigned long long *d_guide_cnt;
     // staging for the *_host entries and workspace for the renderer (grown on demand)
     void *stage[4];
     size_t stage_bytes[4];
@@ -586,7 +589,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     m->params = *params;
     m->device = device;
     for (int i = 0; i < 4; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
-    m->d_model = nullptr; m->d_counters = nullptr;
+    m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr;
+    memset(&m->guide, 0, sizeof m->guide);
     m->profiling = false;
     for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
     memset(&m->fast, 0, sizeof m->fast);
@@ -594,6 +598,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     if (st != GPIS_OK) { delete m; return st; }
     hipError_t e = hipMalloc(&m->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&m->d_counters, 2 * sizeof(Counters));
+    if (e == hipSuccess) e = hipMalloc(&m->d_guide_cnt, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(m->d_guide_cnt, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemcpy(m->d_model, &m->host_model, sizeof(DevModel), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(m->d_counters, 0, 2 * sizeof(Counters));
     if (e != hipSuccess) {
@@ -621,6 +627,8 @@ extern "C" int gpis_destroy(gpis_medium *m)
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
     fast_table_free(&m->fast);
+    guide_free(&m->guide);
+    if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
     for (int k = 0; k < 2; ++k)
         for (auto &ev : m->events[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int i = 0; i < 4; ++i)
@@ -676,6 +684,10 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
 {
     if (n == 0) return GPIS_OK;
     ProfScope prof(m, 0, s);
+    if (m->guide.enabled) {
+        k_guided_sample_distance<<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
+        return launch_check("k_guided_sample_distance");
+    }
     if (m->fast.enabled) {
         int st = fast_sample_distance(m->d_model, &m->fast, n, rays, out, coeff, mask, m->d_counters, s);
         if (st != GPIS_OK) return set_err(st, "fast sample_distance launch failed");
@@ -688,6 +700,10 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
 {
     if (n == 0) return GPIS_OK;
     ProfScope prof(m, 1, s);
+    if (m->guide.enabled) {
+        k_guided_transmittance<<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
+        return launch_check("k_guided_transmittance");
+    }
     if (m->fast.enabled) {
         int st = fast_transmittance(m->d_model, &m->fast, n, rays, visible, mask, m->d_counters + 1, s);
         if (st != GPIS_OK) return set_err(st, "fast transmittance launch failed");
@@ -902,7 +918,67 @@ extern "C" int gpis_reset_counters(gpis_medium *m)
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(m->d_counters, 0, 2 * sizeof(Counters)));
+    HIP_TRY(hipMemset(m->d_guide_cnt, 0, 4 * sizeof(unsigned long long)));
     for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
+    return GPIS_OK;
+}
+
+// ---- guide field ---------------------------------------------------------------------------
+extern "C" int gpis_build_guide(gpis_medium *m, int half_extent_cells, int points_per_cell)
+{
+    CHECK_ARGS(m);
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!m->fast.enabled)
+        return set_err(GPIS_ERR_UNSUPPORTED, "gpis_build_guide: the medium is not covered by the wave-cooperative path (single_realization, 3D, stationary SE, diagonal anisotropy)");
+    int st = guide_build(m->host_model, m->d_model, m->fast, half_extent_cells, points_per_cell, &m->guide);
+    if (st != GPIS_OK)
+        return set_err(st, "gpis_build_guide(half=%d, ppc=%d) failed: %s", half_extent_cells, points_per_cell,
+                       st == GPIS_ERR_UNSUPPORTED ? "unsupported arguments" : hipGetErrorString(hipGetLastError()));
+    return GPIS_OK;
+}
+extern "C" int gpis_drop_guide(gpis_medium *m)
+{
+    CHECK_ARGS(m);
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    guide_free(&m->guide);
+    return GPIS_OK;
+}
+extern "C" int gpis_get_guide_steps(gpis_medium *m, uint64_t *n_guide)
+{
+    CHECK_ARGS(m && n_guide);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, m->d_guide_cnt, sizeof v, hipMemcpyDeviceToHost));
+    *n_guide = v;
+    return GPIS_OK;
+}
+extern "C" int gpis_guide_selfcheck(gpis_medium *m, size_t n, const float *points3, uint64_t *checked, uint64_t *violations,
+                                    float *max_ratio, float *mean_bound, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || points3));
+    if (!m->guide.enabled) return set_err(GPIS_ERR_UNSUPPORTED, "gpis_guide_selfcheck: no guide field built");
+    HIP_TRY(hipSetDevice(m->device));
+    // scratch: [1..2] = checked/violations, word 3 = {max ratio bits, sum of bounds}
+    unsigned long long *st = m->d_guide_cnt + 1;
+    HIP_TRY(hipMemsetAsync(st, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
+    if (n)
+        k_guide_selfcheck<<<grid_of(n, kFastBlock), kFastBlock, 0, (hipStream_t)stream>>>(m->d_model, m->fast, m->guide, n, points3, st, (float *)(st + 2), (float *)(st + 2) + 1);
+    int rc = launch_check("k_guide_selfcheck");
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long h[3];
+    HIP_TRY(hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost));
+    float fr[2];
+    memcpy(fr, &h[2], sizeof fr);
+    if (checked) *checked = h[0];
+    if (violations) *violations = h[1];
+    if (max_ratio) *max_ratio = fr[0];
+    if (mean_bound) *mean_bound = h[0] ? fr[1] / (float)h[0] : 0.f;
     return GPIS_OK;
 }
 

@@ -1,0 +1,71 @@
+"""The certified guide field: its error bound must hold everywhere (self-check against the exact
+lattice sum on ~10^6 points), and the guided march must give the same bytes as the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from gpu_util import to_dev, scene_rays, shadow_rays_from
+
+pytestmark = pytest.mark.gpu
+
+
+def _cluster_points(rng, n_groups, half):
+    """groups of 64 points within a fraction of a cell (the evaluator's coherent case), group centres
+    uniform over the tabulated volume, including cell faces and the volume's border"""
+    centres = rng.uniform(-half + 0.05, half - 0.15, (n_groups, 1, 3))
+    centres[:8, 0, :] = np.round(centres[:8, 0, :])            # on lattice cell corners
+    pts = centres + rng.uniform(0, 0.08, (n_groups, 64, 3))
+    return pts.reshape(-1, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize("cfg,ppc", [("C1", 32), ("C1", 8), ("C0", 16)])
+def test_guide_bound_holds(pkg, cfg, ppc):
+    import torch
+    half = 5
+    med = pkg.Medium(pkg.params_for_config(cfg))
+    med.build_guide(half, ppc)
+    rng = np.random.default_rng(7)
+    pts = _cluster_points(rng, 16384, half)
+    d = to_dev(pts)
+    checked, bad, ratio, bound = med.guide_selfcheck(d.data_ptr(), len(pts))
+    print("guide %s ppc=%d: checked %d, violations %d, max |err|/bound %.3f, mean bound %.3f" % (cfg, ppc, checked, bad, ratio, bound))
+    assert checked > 0.95 * len(pts)
+    assert bad == 0 and ratio < 1.0
+    assert 0 < bound < 50
+
+
+def test_guided_march_matches_oracle_and_saves_evaluations(pkg, ob):
+    params = pkg.params_for_config("C1")
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    scene = ob.default_scene_s(480, 270, 2)
+    rays, us = scene_rays(ob, orc, scene, step=6)
+    want = orc.sample_distance(rays)
+    sh = shadow_rays_from(ob, scene, rays, us, want)
+    vis_o = orc.transmittance(sh)
+    med.reset_counters()
+    base = med.sample_distance(rays)
+    e_exact = med.counters()[0]
+    med.build_guide(16, 32)
+    med.reset_counters()
+    got = med.sample_distance(rays)
+    e_guided, n_guide = med.counters()[0], med.guide_steps()
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+        assert np.array_equal(got[f], base[f], equal_nan=True), f
+    assert np.array_equal(med.transmittance(sh), vis_o)
+    print("exact evaluations: %d unguided, %d guided (+%d guide lookups) for %d segments" % (e_exact, e_guided, n_guide, len(rays)))
+    assert e_guided < 0.35 * e_exact
+    med.drop_guide()
+    again = med.sample_distance(rays)
+    assert np.array_equal(again["t"], want["t"])
+
+
+def test_guide_argument_errors(pkg):
+    med = pkg.Medium(pkg.params_for_config("C1"))
+    with pytest.raises(RuntimeError, match="gpis_build_guide"):
+        med.build_guide(16, 12)          # points per cell must be 8/16/32/64
+    p = pkg.params_for_config("C2")      # per-path realizations: no shared field exists
+    med2 = pkg.Medium(p)
+    with pytest.raises(RuntimeError, match="not covered"):
+        med2.build_guide(8, 8)

@@ -86,7 +86,7 @@ def test_eval_value_gradient_bit_exact(env, cfg):
     assert e_g >= 2 * len(q)
 
 
-PATHS = ["fast", "fast_gen", "fast_small_table", "generic"]
+PATHS = ["fast", "fast_gen", "fast_small_table", "generic", "guided_coarse", "guided_fine_partial"]
 
 
 def _medium(pkg, params, path):
@@ -95,10 +95,14 @@ def _medium(pkg, params, path):
       fast_gen         wave-cooperative kernels, every cell generated on the fly (no table)
       fast_small_table a 4-cell half-extent table: most cells of scene S fall outside it, so table
                        cells and generated cells are mixed inside one evaluation
-      generic          lane-per-ray kernels"""
+      generic          lane-per-ray kernels
+      guided_coarse    guided march, guide field over the whole scene at 8 points per cell (loose
+                       bound: many steps fall back to the exact evaluation)
+      guided_fine_partial  guided march, 32 points per cell but only |u| < 6 cells tabulated: rays
+                       leave and re-enter the tabulated volume"""
     import os
     env = {"generic": {"GPIS_DISABLE_FAST": "1"}, "fast_gen": {"GPIS_DISABLE_TABLE": "1"},
-           "fast_small_table": {"GPIS_TABLE_HALF_EXTENT": "4"}, "fast": {}}[path]
+           "fast_small_table": {"GPIS_TABLE_HALF_EXTENT": "4"}, "fast": {}}.get(path, {})
     keys = ("GPIS_DISABLE_FAST", "GPIS_DISABLE_TABLE", "GPIS_TABLE_HALF_EXTENT")
     for k in keys:
         os.environ.pop(k, None)
@@ -109,6 +113,10 @@ def _medium(pkg, params, path):
         for k in keys:
             os.environ.pop(k, None)
     assert int(med.derived()["fast_path"]) == (0 if path == "generic" else 1)
+    if path == "guided_coarse":
+        med.build_guide(16, 8)
+    elif path == "guided_fine_partial":
+        med.build_guide(6, 32)
     return med
 
 
@@ -434,6 +442,9 @@ def test_render_scene_s_small(env, path):
         assert s_g == s_o
         if path == "generic":
             assert e_g == e_o
+        elif path.startswith("guided"):
+            # certified steps replace exact evaluations: fewer evaluations, some guide lookups
+            assert e_g < e_o and med.guide_steps() > 0
         else:
             # the cooperative transmittance kernel skips the one end-of-segment evaluation whose
             # result cannot reach the output (gradient on a hit, lastVal on exit: GPM.cpp:371-392)
