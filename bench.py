@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--shard", choices=["spp", "rows"], default="spp")
+    ap.add_argument("--guide", default="16:32", help="certified guide field 'half_extent_cells:points_per_cell' for "
+                    "single-realization media, or 'off' (built once before the timed region, 4.3 GB at 16:32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,6 +121,13 @@ def main():
 
     med = pkg.Medium(params, device=local_rank)
     lib = med.L.lib
+    guide_info = None
+    if args.guide != "off" and int(med.derived()["fast_path"]):
+        half, ppc = (int(x) for x in args.guide.split(":"))
+        t_g = time.perf_counter()
+        med.build_guide(half, ppc)
+        guide_info = {"half_extent_cells": half, "points_per_cell": ppc, "bytes": (2 * half * ppc) ** 3 * 4,
+                      "build_s": time.perf_counter() - t_g}
     W, H, spp = args.width, args.height, args.spp
     scene = np.zeros((), dtype=pkg.SCENE_S)
     lib.gpis_default_scene_s(scene.ctypes.data, W, H, spp)
@@ -158,6 +167,7 @@ def main():
     dt_max = float(tmax.item())
 
     prof = [med.kernel_profile(k) for k in (0, 1)]     # (ms, launches, n_eval, n_seg)
+    n_guide = med.guide_steps() if guide_info else 0
     if rank == 0:
         total_samples = W * H * pkg.dist.total_spp(scene, world, args.shard) * args.steps
         b_eval = algorithmic_bytes_per_eval(params)
@@ -167,7 +177,7 @@ def main():
         bytes_alg = n_eval * b_eval + n_seg * B_SEG
         achieved = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         fast = int(med.derived()["fast_path"])
-        kernel = ("k_fast_" if fast else "k_") + names[dom]
+        kernel = ("k_guided_" if guide_info else ("k_fast_" if fast else "k_")) + names[dom]
         res = {
             "metric": "Msamples/s (primary rays x spp / s)", "value": total_samples / dt_max / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
@@ -176,7 +186,9 @@ def main():
                                    "impulse_density=%d, ctx=renewal, single_realization)" % (args.config, W, H, spp, int(params["impulse_density"]))
                        if args.config == "C1" else "%s: scene S %dx%d, %d spp/GPU" % (args.config, W, H, spp),
                        "sharding": ("%s shards per rank + reduce(sum) to rank 0" % args.shard) if world > 1 else "single GPU",
-                       "kernel_path": "fast (wave-cooperative cells in LDS)" if fast else "generic (on-the-fly impulses)"},
+                       "kernel_path": ("guided (certified guide field + wave-cooperative exact evaluations)" if guide_info else
+                                       "fast (wave-cooperative)") if fast else "generic (on-the-fly impulses)",
+                       "guide": guide_info},
             "roofline": {
                 "bound": "hbm", "kernel": kernel,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -185,6 +197,7 @@ def main():
                 "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                 "bytes_per_eval": b_eval, "bytes_per_segment": B_SEG, "n_eval": n_eval, "n_seg": n_seg,
                 "evals_per_s": (prof[0][2] + prof[1][2]) / dt_max,
+                "guide_lookups": n_guide, "guide_lookups_per_s": n_guide / dt_max,
                 "kernel_ms": {names[0]: prof[0][0], names[1]: prof[1][0]},
                 "note": "impulses are generated or gathered on chip; the binding roof is VALU integer/fp32 issue, "
                         "the HBM figure uses SURVEY.md 8d's algorithmic-bytes definition",
