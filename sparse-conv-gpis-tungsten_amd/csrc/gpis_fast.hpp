@@ -236,7 +236,14 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
     }
 #endif
     FSTAT(0, 1);
-    FSTAT(1, __popcll(__ballot(active)));
+#ifdef GPIS_FAST_STATS
+    {   // histogram of active lanes per cooperative evaluation: bins 1-2, 3-4, 5-8, 9-16, 17-32, 33-64
+        const int na = __popcll(__ballot(active));
+        const int bin = na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : 5;
+        FSTAT(9 + bin, 1);
+        FSTAT(1, na);
+    }
+#endif
     // cells are addressed with int coordinates; keep far away from overflow and from float→int UB
     const float lim = 1.0e6f;
     bool sane = bx0 > -lim && bx1 < lim && by0 > -lim && by1 < lim && bz0 > -lim && bz1 < lim;

@@ -15,13 +15,14 @@
 // sign and costs one 8-tap lookup instead of 27*rho kernel evaluations; all other steps run the exact
 // cooperative evaluation, so every output is bit-identical to the exact path.
 //
-// Error budget for u in the cell anchored at grid point g (m = h*sqrt(3) = the cell diagonal), all
+// Error budget for u in the cell anchored at grid point g, measured from the cell CENTRE c = g + h/2
+// (delta_i(c) = impulse offset seen from c, m = h*sqrt(3)/2 = half the cell diagonal), all
 // sums over impulses i, every term an upper bound valid on the whole cell:
-//   truncation  T = sum_{|delta_i(g)| >= 1-1e-5-m} exp(-amin * max(1-1e-5, |delta_i(g)|-m)^2)
+//   truncation  T = sum_{|delta_i(c)| >= 1-1e-5-m} exp(-amin * max(1-1e-5, |delta_i(c)|-m)^2)
 //                 (the reference drops impulse i when its fp32 |delta|^2 < 1 test fails; whatever it
 //                  drops has |delta| >= 1-1e-5 and contributes at most this much)
-//   interpolation E = (h^2/8) * sum_a sum_i max(4 alpha_a^2 (|delta_a(g)|+h)^2 - 2 alpha_a, 2 alpha_a)
-//                                          * exp(-amin * max(|delta_i(g)|-m, 0)^2)
+//   interpolation E = (h^2/8) * sum_a sum_i max(4 alpha_a^2 (|delta_a(c)|+h/2)^2 - 2 alpha_a, 2 alpha_a)
+//                                          * exp(-amin * max(|delta_i(c)|-m, 0)^2)
 //                 (multilinear interpolation error <= sum_a h^2/8 sup|d_aa S|, and
 //                  d_aa exp(-q) = (4 alpha_a^2 delta_a^2 - 2 alpha_a) exp(-q))
 //   culled      impulses farther than r_c from the block are skipped: n_culled * exp(-amin r_c^2)
@@ -66,7 +67,9 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
     const int c0x = (int)floorf(lox), c0y = (int)floorf(loy), c0z = (int)floorf(loz);   // same lattice cell for the whole block
     const float ax = F.alpha[0], ay = F.alpha[1], az = F.alpha[2];
     const float amin = fminf(ax, fminf(ay, az)), amax = fmaxf(ax, fmaxf(ay, az));
-    const float m = h * 1.7320509f;
+    // bounds are taken around the CENTRE of the cell anchored at the grid point: every u of the cell is
+    // within mc = h*sqrt(3)/2 (+ slack for a lookup position that is off by rounding) of it
+    const float mc = h * 0.8660254f + 1e-4f, hh = 0.5f * h + 1e-4f;
     const uint32_t n = M.n_impulses;
     const int H = T.half, S = T.stride;
     const unsigned tside = 2u * (unsigned)H;
@@ -97,19 +100,20 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
                     const float iw = lane_f(pw, k);
                     // delta = u - (cell + p_i)
                     const float ddx = ux - ((float)cx + lane_f(px, k)), ddy = uy - ((float)cy + lane_f(py, k)), ddz = uz - ((float)cz + lane_f(pz, k));
-                    const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
                     const float q = ax * ddx * ddx + ay * ddy * ddy + az * ddz * ddz;
                     Ssum += iw * __expf(-q);
-                    const float dn = sqrtf(d2);
-                    const float dm = fmaxf(dn - m, 0.f);
+                    // the same impulse seen from the cell centre (delta_c = delta + h/2)
+                    const float ccx = ddx + 0.5f * h, ccy = ddy + 0.5f * h, ccz = ddz + 0.5f * h;
+                    const float dn = sqrtf(ccx * ccx + ccy * ccy + ccz * ccz);
+                    const float dm = fmaxf(dn - mc, 0.f);
                     const float e_dm = __expf(-amin * dm * dm);
-                    const float adx = fabsf(ddx) + h, ady = fabsf(ddy) + h, adz = fabsf(ddz) + h;
+                    const float adx = fabsf(ccx) + hh, ady = fabsf(ccy) + hh, adz = fabsf(ccz) + hh;
                     const float cxx = fmaxf(4.f * ax * ax * adx * adx - 2.f * ax, 2.f * ax);
                     const float cyy = fmaxf(4.f * ay * ay * ady * ady - 2.f * ay, 2.f * ay);
                     const float czz = fmaxf(4.f * az * az * adz * adz - 2.f * az, 2.f * az);
                     Esum += (cxx + cyy + czz) * e_dm;
-                    if (dn >= 1.f - 1e-5f - m) {
-                        const float dt = fmaxf(1.f - 1e-5f, dn - m);
+                    if (dn >= 1.f - 1e-5f - mc) {
+                        const float dt = fmaxf(1.f - 1e-5f, dn - mc);
                         Tsum += __expf(-amin * dt * dt);
                     }
                 }

@@ -16,16 +16,21 @@ w, h, spp = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (480, 270,
 med = pkg.Medium(pkg.params_for_config(sys.argv[4] if len(sys.argv) > 4 else "C1"), lib=lib)
 scene = np.zeros((), dtype=pkg.SCENE_S)
 lib.lib.gpis_default_scene_s(scene.ctypes.data, w, h, spp)
+if len(sys.argv) > 5 and sys.argv[5] != "off":
+    half, ppc = (int(x) for x in sys.argv[5].split(":"))
+    med.build_guide(half, ppc)
 rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
 med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, None)
 torch.cuda.synchronize()
 out = (ctypes.c_uint64 * 16)()
 lib.lib.gpis_debug_fast_stats(out)
-names = ["wave_evals", "active_lanes", "cells_visited", "cells_mine", "cells_cand", "candidates", "union_pass", "lane_pass", "incoherent"]
+names = ["wave_evals", "active_lanes", "cells_visited", "cells_mine", "cells_cand", "candidates", "union_pass", "lane_pass", "incoherent",
+         "lanes_1_2", "lanes_3_4", "lanes_5_8", "lanes_9_16", "lanes_17_32", "lanes_33_64"]
 st = dict(zip(names, list(out)))
 e = max(st["wave_evals"], 1)
 print(st)
 print("per wave-eval: active lanes %.1f, cells visited %.1f, processed %.1f, with candidates %.1f, candidates %.1f, bodies %.1f, "
       "lane-passes/body %.1f, incoherent %.4f" % (st["active_lanes"] / e, st["cells_visited"] / e, st["cells_mine"] / e, st["cells_cand"] / e,
                                                  st["candidates"] / e, st["union_pass"] / e, st["lane_pass"] / max(st["union_pass"], 1), st["incoherent"] / e))
-print("lane evals", med.counters())
+print("lane evals", med.counters(), "guide steps", med.guide_steps())
+print("active lanes per exact wave-eval: %.1f" % (med.counters()[0] / e))
