@@ -6,29 +6,28 @@
 // only needs the SIGN of sigma*N/norm + mean at almost every step; the value matters at the crossing
 // step, the step before it, during refinement and at the segment end.  So:
 //
-//   G   = trilinear interpolation of samples of the SMOOTH sum S(u) = sum_i w_i exp(-q_i(u)) over all
-//         impulses (no unit-ball cut-off), q_i = sum_a alpha_a delta_a^2, delta = u - (cell + p_i),
-//         alpha_a = A_a R^2, on a grid of spacing h = 1/ppc cells,
-//   Err = a RIGOROUS bound on |N_ref(u) - G(u)| for every u of a 4x4x4-point block, stored per block.
+//   V(g) = the lattice sum itself (with its unit-ball cut-off) sampled on a grid of spacing h = 1/ppc
+//          cells:  V(g) = sum_i [|delta_i(g)| < 1] w_i exp(-q_i(g)),  q_i = sum_a alpha_a delta_a^2,
+//          delta = g - (cell + p_i), alpha_a = A_a R^2;   G(u) = trilinear interpolation of V,
+//   Err  = a RIGOROUS bound on |N_ref(u) - G(u)| for every u of a 4x4x4-point block, stored per block.
 //
 // A march step whose |sigma*G/norm + mean| exceeds sigma*Err/norm (+ rounding slack) has a certified
 // sign and costs one 8-tap lookup instead of 27*rho kernel evaluations; all other steps run the exact
 // cooperative evaluation, so every output is bit-identical to the exact path.
 //
-// Error budget for u in the cell anchored at grid point g, measured from the cell CENTRE c = g + h/2
-// (delta_i(c) = impulse offset seen from c, m = h*sqrt(3)/2 = half the cell diagonal), all
-// sums over impulses i, every term an upper bound valid on the whole cell:
-//   truncation  T = sum_{|delta_i(c)| >= 1-1e-5-m} exp(-amin * max(1-1e-5, |delta_i(c)|-m)^2)
-//                 (the reference drops impulse i when its fp32 |delta|^2 < 1 test fails; whatever it
-//                  drops has |delta| >= 1-1e-5 and contributes at most this much)
-//   interpolation E = (h^2/8) * sum_a sum_i max(4 alpha_a^2 (|delta_a(c)|+h/2)^2 - 2 alpha_a, 2 alpha_a)
-//                                          * exp(-amin * max(|delta_i(c)|-m, 0)^2)
-//                 (multilinear interpolation error <= sum_a h^2/8 sup|d_aa S|, and
-//                  d_aa exp(-q) = (4 alpha_a^2 delta_a^2 - 2 alpha_a) exp(-q))
-//   culled      impulses farther than r_c from the block are skipped: n_culled * exp(-amin r_c^2)
-//                 (+ their share of E), cells beyond the 5x5x5 block: 218 * n * exp(-4 amin)
-//   rounding    fp32 accumulation of <= ~700 terms, v_exp_f32, the lerp: 5e-4 absolute
-// amin = min_a alpha_a.  Bounds are accumulated in fp32 and inflated by 1e-3 relative.
+// Error budget for the cell C anchored at grid point g (c = its centre, m = half its diagonal, r_i =
+// |delta_i(c)|, amin = min_a alpha_a).  Every impulse falls in exactly one class:
+//   inside  r_i + m < 1 - 1e-5 : its indicator is 1 at u and at all 8 corners, so it contributes a smooth
+//           term whose multilinear interpolation error is <= sum_a h^2/8 sup_C |d_aa w e^{-q}|, with
+//           d_aa e^{-q} = (4 alpha_a^2 delta_a^2 - 2 alpha_a) e^{-q}  bounded by
+//           max(4 alpha_a^2 (|delta_a(c)| + h/2)^2 - 2 alpha_a, 2 alpha_a) * exp(-amin max(r_i - m, 0)^2);
+//   outside r_i - m >= 1 + 1e-5 : indicator 0 everywhere on C (also for the reference's fp32 test): nothing;
+//   shell   otherwise: at u the reference adds either 0 or w e^{-q(u)}, the interpolant a convex
+//           combination of 0 and w e^{-q(corner)}: they differ by at most sup_C e^{-q} <= exp(-amin max(r_i - m, 0)^2).
+//   rounding: fp32 accumulation, v_exp_f32, the reference's own fp32 kernel arguments, the lerp: 5e-4
+//           absolute + 1e-3 relative.
+// Impulses farther than 1 + 1e-4 from the block's cells are "outside" for every cell of the block and
+// are skipped without any error term.
 #pragma once
 #include "gpis_fast.hpp"
 
@@ -47,7 +46,7 @@ struct GuideField {
     int enabled;
 };
 
-constexpr float kGuideCullRadius = 1.75f;
+constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the block's cells an impulse contributes exactly 0
 
 // one wave = one 4x4x4 block of grid points
 __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t block_offset)
@@ -74,11 +73,17 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
     const int H = T.half, S = T.stride;
     const unsigned tside = 2u * (unsigned)H;
     float Ssum = 0.f, Tsum = 0.f, Esum = 0.f;
-    uint32_t n_culled = 0;
     for (int dx = -2; dx <= 2; ++dx)
         for (int dy = -2; dy <= 2; ++dy)
             for (int dz = -2; dz <= 2; ++dz) {
                 const int cx = c0x + dx, cy = c0y + dy, cz = c0z + dz;
+                // a whole lattice cell farther than the cut-off from the block's cells cannot matter
+                const float bx0 = (float)cx - (lox + 4.f * h), bx1 = lox - (float)(cx + 1);
+                const float by0 = (float)cy - (loy + 4.f * h), by1 = loy - (float)(cy + 1);
+                const float bz0 = (float)cz - (loz + 4.f * h), bz1 = loz - (float)(cz + 1);
+                const float ex = fmaxf(fmaxf(bx0, bx1), 0.f), ey = fmaxf(fmaxf(by0, by1), 0.f), ez = fmaxf(fmaxf(bz0, bz1), 0.f);
+                if (ex * ex + ey * ey + ez * ez >= kGuideCullRadius * kGuideCullRadius)
+                    continue;
                 float px, py, pz, pw;
                 if (T.cells && (unsigned)(cx + H) < tside && (unsigned)(cy + H) < tside && (unsigned)(cz + H) < tside) {
                     const size_t idx = (((size_t)(cx + H) * tside + (size_t)(cy + H)) * tside + (size_t)(cz + H)) * (size_t)S;
@@ -87,41 +92,42 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
                 } else {
                     gen_impulse((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, M.seed, kJump4.A[lane], kJump4.C[lane], px, py, pz, pw);
                 }
-                // impulse position relative to the block's low corner, distance to the expanded box
+                // impulse position relative to the block's low corner, distance to the box of the block's cells
                 const float rx = (float)cx + px - lox, ry = (float)cy + py - loy, rz = (float)cz + pz - loz;
                 const float gx = fmaxf(fmaxf(-rx, rx - 4.f * h), 0.f), gy = fmaxf(fmaxf(-ry, ry - 4.f * h), 0.f), gz = fmaxf(fmaxf(-rz, rz - 4.f * h), 0.f);
-                const bool valid_k = (uint32_t)lane < n;
-                const bool near_k = valid_k && (gx * gx + gy * gy + gz * gz) < (kGuideCullRadius + 1e-3f) * (kGuideCullRadius + 1e-3f);
+                const bool near_k = (uint32_t)lane < n && (gx * gx + gy * gy + gz * gz) < kGuideCullRadius * kGuideCullRadius;
                 unsigned long long cand = __ballot(near_k);
-                n_culled += (uint32_t)__popcll(__ballot(valid_k && !near_k));
                 while (cand) {
                     const int k = __builtin_ctzll(cand);
                     cand &= cand - 1ULL;
                     const float iw = lane_f(pw, k);
-                    // delta = u - (cell + p_i)
+                    // delta = g - (cell + p_i)
                     const float ddx = ux - ((float)cx + lane_f(px, k)), ddy = uy - ((float)cy + lane_f(py, k)), ddz = uz - ((float)cz + lane_f(pz, k));
+                    const float rg2 = ddx * ddx + ddy * ddy + ddz * ddz;
                     const float q = ax * ddx * ddx + ay * ddy * ddy + az * ddz * ddz;
-                    Ssum += iw * __expf(-q);
+                    if (rg2 < 1.0f)
+                        Ssum += iw * __expf(-q);
                     // the same impulse seen from the cell centre (delta_c = delta + h/2)
                     const float ccx = ddx + 0.5f * h, ccy = ddy + 0.5f * h, ccz = ddz + 0.5f * h;
-                    const float dn = sqrtf(ccx * ccx + ccy * ccy + ccz * ccz);
-                    const float dm = fmaxf(dn - mc, 0.f);
+                    const float rc = sqrtf(ccx * ccx + ccy * ccy + ccz * ccz);
+                    if (rc - mc >= 1.f + 1e-5f)
+                        continue;                                      // outside on the whole cell
+                    const float dm = fmaxf(rc - mc, 0.f);
                     const float e_dm = __expf(-amin * dm * dm);
-                    const float adx = fabsf(ccx) + hh, ady = fabsf(ccy) + hh, adz = fabsf(ccz) + hh;
-                    const float cxx = fmaxf(4.f * ax * ax * adx * adx - 2.f * ax, 2.f * ax);
-                    const float cyy = fmaxf(4.f * ay * ay * ady * ady - 2.f * ay, 2.f * ay);
-                    const float czz = fmaxf(4.f * az * az * adz * adz - 2.f * az, 2.f * az);
-                    Esum += (cxx + cyy + czz) * e_dm;
-                    if (dn >= 1.f - 1e-5f - mc) {
-                        const float dt = fmaxf(1.f - 1e-5f, dn - mc);
-                        Tsum += __expf(-amin * dt * dt);
+                    if (rc + mc < 1.f - 1e-5f) {                       // inside on the whole cell
+                        const float adx = fabsf(ccx) + hh, ady = fabsf(ccy) + hh, adz = fabsf(ccz) + hh;
+                        const float cxx = fmaxf(4.f * ax * ax * adx * adx - 2.f * ax, 2.f * ax);
+                        const float cyy = fmaxf(4.f * ay * ay * ady * ady - 2.f * ay, 2.f * ay);
+                        const float czz = fmaxf(4.f * az * az * adz * adz - 2.f * az, 2.f * az);
+                        Esum += (cxx + cyy + czz) * e_dm;
+                    } else {                                           // the cut-off sphere crosses the cell
+                        Tsum += e_dm;
                     }
                 }
             }
-    const float e_cull = __expf(-amin * kGuideCullRadius * kGuideCullRadius);
-    const float far_cells = 218.f * (float)n * __expf(-4.f * amin);
-    float err = (h * h * 0.125f) * (Esum + (float)n_culled * 3.f * (4.f * amax * amax * 9.f) * e_cull) + Tsum + (float)n_culled * e_cull + far_cells;
+    float err = (h * h * 0.125f) * Esum + Tsum;
     err = err * 1.001f + 5e-4f;
+    (void)amax;
     F.G[((size_t)ix * F.side + (size_t)iy) * F.side + (size_t)iz] = Ssum;
     float emax = err;
     for (int off = 32; off > 0; off >>= 1) emax = fmaxf(emax, __shfl_xor(emax, off, 64));
