@@ -373,6 +373,65 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
     return sum;
 }
 
+// noise3D VALUE for ONE query (the one held by lane `src`, src wave-uniform) with the wave turned
+// sideways: lane k owns impulse k of the current cell and evaluates its kernel against the single query
+// point; the cell sum is then accumulated over the passing lanes in ascending k (a v_readlane chain),
+// which is the reference's order (SCN.cpp:383-392), and cells in dx,dy,dz order (SCN.cpp:368-371).
+// ~2.4k instructions per query against ~10k for a cooperative evaluation: used when only a few lanes
+// of a wave need an exact value.  The result is wave-uniform.
+GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds &lds, int src, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const V3 pg = p / R;
+    const V3 fl = v3(floorf(pg.x), floorf(pg.y), floorf(pg.z));
+    const V3 fr = pg - fl;
+    // the query of lane `src`, broadcast
+    const float fx = lane_f(fr.x, src), fy = lane_f(fr.y, src), fz = lane_f(fr.z, src);
+    const float qx = lane_f(fl.x, src), qy = lane_f(fl.y, src), qz = lane_f(fl.z, src);
+    if (!(fabsf(qx) < 1.0e6f && fabsf(qy) < 1.0e6f && fabsf(qz) < 1.0e6f)) {
+        // outside the range where cells are addressed with ints: the per-lane generator handles it
+        float r = 0.f;
+        if (lane == src)
+            r = noise3d_per_lane(M, p, seed, R, A0, A1, A2).v;
+        return lane_f(r, src);
+    }
+    const int ci0 = (int)qx, cj0 = (int)qy, ck0 = (int)qz;
+    const uint32_t n = M.n_impulses;
+    const int H = T.half, S = T.stride;
+    const unsigned side = 2u * (unsigned)H;
+    float sum = 0.f;
+    for (int di = -1; di <= 1; ++di)
+        for (int dj = -1; dj <= 1; ++dj)
+            for (int dk = -1; dk <= 1; ++dk) {
+                const int ci = ci0 + di, cj = cj0 + dj, ck = ck0 + dk;
+                float px, py, pz, pw;
+                if (T.cells && (unsigned)(ci + H) < side && (unsigned)(cj + H) < side && (unsigned)(ck + H) < side) {
+                    const size_t idx = (((size_t)(ci + H) * side + (size_t)(cj + H)) * side + (size_t)(ck + H)) * (size_t)S;
+                    const float4 v = T.cells[idx + (size_t)(lane & (S - 1))];
+                    px = v.x; py = v.y; pz = v.z; pw = v.w;
+                } else {
+                    gen_impulse((uint32_t)ci, (uint32_t)cj, (uint32_t)ck, seed, kJump4.A[lane], kJump4.C[lane], px, py, pz, pw);
+                }
+                const V3 pc = v3(fx, fy, fz) - v3((float)di, (float)dj, (float)dk);
+                const bool pass = (uint32_t)lane < n && length_sq(pc - v3(px, py, pz)) < 1.0f;
+                unsigned long long m = __ballot(pass);
+                if (m == 0ULL)
+                    continue;
+                const V3 ab = R * pc - R * v3(px, py, pz);
+                const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
+                const float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
+                const float c = pw * expf_glibc_lds(lds, -absq);
+                float cell = 0.f;
+                while (m) {
+                    const int k = __builtin_ctzll(m);
+                    m &= m - 1ULL;
+                    cell = cell + lane_f(c, k);
+                }
+                sum = sum + cell;
+            }
+    return sum;
+}
+
 // evaluateNoise3D for the stationary single-realization case (SCN.cpp:101-116, 251-260, 291-320):
 // per-lane transforms exactly as the generic path, the noise3D sum cooperatively.
 // `coord` is the ray's isotropic-ray frame (SCN.cpp:296-297), constant along the segment and hoisted
@@ -401,6 +460,28 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &ld
 GPIS_DEV float coop_evaluate_value(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
 {
     float nv = coop_eval_noise3d<false>(M, T, lds, active, p, coord, n_eval).v;
+    double mean;
+    int id;
+    mean_weight_space(M, to_d(p), mean, id);
+    gp_id = id;
+    if (M.surf_vol_phase_separate)
+        gp_id = (1.f < M.surf_vol_phase_amp_thresh) ? 0 : 1;
+    return (float)((double)(M.sigma * nv) + mean);
+}
+// evaluateValue (SCN.cpp:73-89) for the single lane `src` through solo_noise3d_value; the value is
+// delivered in lane src's return value (other lanes get an unspecified number).
+GPIS_DEV float solo_evaluate_value(const DevModel &M, const FastTable &T, FastLds &lds, int src, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    float nv;
+    if (!M.iso3d) {
+        float A0 = M.invcov_world[0] / 1.f / 1.f * 0.5f, A1 = M.invcov_world[4] / 1.f / 1.f * 0.5f, A2 = M.invcov_world[8] / 1.f / 1.f * 0.5f;
+        nv = solo_noise3d_value(M, T, lds, src, p, M.seed, M.radius_world, A0, A1, A2) / M.norm3d_world;
+    } else {
+        V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
+        nv = solo_noise3d_value(M, T, lds, src, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f) / M.norm3d_iso;
+    }
+    if (lane == src) n_eval++;
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);

@@ -46,6 +46,7 @@ struct GuideField {
     int enabled;
 };
 
+constexpr int kSoloMaxLanes = 3;            // clusters up to this size use the sideways evaluator
 constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the block's cells an impulse contributes exactly 0
 
 // one wave = one 4x4x4 block of grid points
@@ -337,7 +338,21 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         // the lead lane is always in its own cluster, so every round retires at least one request
         const bool in_cluster = need && cx >= ax0 && cx <= ax0 + 1 && cy >= ay0 && cy <= ay0 + 1 && cz >= az0 && cz <= az0 + 1;
         int gp_new;
-        const float fv = coop_evaluate_value(M, T, lds, in_cluster, pq, coord, gp_new, n_eval);
+        float fv;
+        const unsigned long long cl_mask = __ballot(in_cluster);
+        if (__popcll(cl_mask) <= kSoloMaxLanes) {
+            // few requests: one sideways (lane = impulse) evaluation per requesting lane
+            fv = 0.f;
+            gp_new = 0;
+            for (unsigned long long mm = cl_mask; mm; mm &= mm - 1ULL) {
+                const int src = __builtin_ctzll(mm);
+                int gpx;
+                const float v = solo_evaluate_value(M, T, lds, src, pq, coord, gpx, n_eval);
+                if ((int)(threadIdx.x & 63) == src) { fv = v; gp_new = gpx; }
+            }
+        } else {
+            fv = coop_evaluate_value(M, T, lds, in_cluster, pq, coord, gp_new, n_eval);
+        }
         if (in_cluster) {
             gp = gp_new;
             const double f = (double)fv;
