@@ -351,6 +351,19 @@ void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint
 int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum,
                         uint32_t *hit_count, void *stream);
 
+/* Multi-bounce wavefront driver on scene S: per sample, up to `max_path_bounces`
+ * medium interactions following PathTracer::traceSample / TraceBase::handleVolume
+ * (PathTracer.cpp:62-75, TraceBase.cpp:539-563):
+ *   sampleDistance (segment word = bounce, PathTracer.cpp:64) → on a hit: next-event estimation of
+ *   the directional light through a state copy with segment+1 (TraceBase.cpp:546-549, 346-386:
+ *   BRDFPhaseFunction/Lambert eval = albedo/pi * cos, Dirac light → no MIS) with one shadow
+ *   transmittance, then a cosine-weighted bounce about the sampled normal (throughput *= albedo).
+ * The bounce direction is drawn by rejection from the unit disk (sqrt only) instead of
+ * SampleWarp::cosineHemisphere's sin/cos so that CPU and GPU agree bit for bit.
+ * Accumulates sum-of-radiance into radiance_sum[height*width] (device pointer). */
+int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, int max_path_bounces, float albedo,
+                              float *radiance_sum, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1951,6 +1951,130 @@ int oracle_render_scene_s(oracle_medium *m, const gpis_scene_s *s, float *radian
     return GPIS_OK;
 }
 
+/* --------------------------------------------------------------------------------------
+ * Multi-bounce estimator on scene S (PathTracer.cpp:62-75, TraceBase.cpp:346-386, 539-563;
+ * BRDFPhaseFunction.cpp:27-96 with a Lambert BSDF, LambertBsdf.cpp:27-47).  Per sample one PCG
+ * stream: jx, jy, then per bounce u_march, [u_shadow when NEE runs], rejection draws of the bounce.
+ * ------------------------------------------------------------------------------------ */
+static const float INV_PI_F = 1.0f / 3.1415926536f;   /* Angle.hpp:12 */
+
+static float scene_paths_sample(oracle_medium *m, oracle_counters *cnt, const gpis_scene_s *s, uint32_t px, uint32_t py, uint32_t spp,
+                                int max_bounces, float albedo)
+{
+    gpis_ray_in ray;
+    float u_unused;
+    if (!oracle_scene_s_primary(s, px, py, spp, &ray, &u_unused))
+        return 0.f;
+    /* re-create the stream after the two pixel-jitter draws */
+    pcg32 g;
+    pcg_set_state(&g, (uint64_t)(uint32_t)(xxhash32_4(px, py, spp, s->scene_seed) + 1u));
+    (void)pcg_next_1d(&g); (void)pcg_next_1d(&g);
+    v3f l = v3_normalized(v3(s->light_dir[0], s->light_dir[1], s->light_dir[2]));
+    float throughput = 1.f, emission = 0.f;
+    for (int bounce = 0; bounce < max_bounces; ++bounce) {
+        ray.segment = (uint32_t)bounce;
+        ray.u_jitter = pcg_next_1d(&g);
+        gpis_seg_out o;
+        sample_distance_one(m, cnt, &ray, &o, NULL);
+        if (!o.ok)
+            break;
+        throughput *= o.weight[0];
+        if (o.exited)
+            break;
+        /* shading frame about the sampled normal (BRDFPhaseFunction::setEventIsectInfo) */
+        double ax = o.aniso[0], ay = o.aniso[1], az = o.aniso[2];
+        double len = sqrt(ax * ax + ay * ay + az * az);
+        v3f n = v3((float)(ax / len), (float)(ay / len), (float)(az / len));
+        frame fr = frame_from_normal(n);
+        v3f dir = v3(ray.dir[0], ray.dir[1], ray.dir[2]);
+        v3f wi = v3_normalized(frame_to_local(&fr, v3(-dir.x, -dir.y, -dir.z)));
+        v3f p = v3(o.p[0], o.p[1], o.p[2]);
+        if (bounce < max_bounces - 1) {   /* NEE, TraceBase.cpp:546-550 */
+            v3f wo = v3_normalized(frame_to_local(&fr, l));
+            if (wi.z > 0.0f && wo.z > 0.0f) {
+                float f = albedo * INV_PI_F * wo.z;
+                float t0, t1;
+                if (sphere_chord(p, l, s->bound_radius, &t0, &t1)) {
+                    gpis_ray_in sh;
+                    memset(&sh, 0, sizeof sh);
+                    sh.pos[0] = p.x; sh.pos[1] = p.y; sh.pos[2] = p.z;
+                    sh.dir[0] = l.x; sh.dir[1] = l.y; sh.dir[2] = l.z;
+                    sh.near_t = 0.f; sh.far_t = t1;
+                    sh.pixel[0] = px; sh.pixel[1] = py; sh.spp = spp;
+                    sh.segment = (uint32_t)bounce + 1;
+                    sh.scene_seed = s->scene_seed;
+                    sh.info_t = ray.info_t + o.sample_t;
+                    sh.u_jitter = pcg_next_1d(&g);
+                    sh.first_scatter = 0;
+                    sh.bounce = ray.bounce + 1;
+                    sh.last_val = o.last_val;
+                    sh.last_gp_id = o.gp_id;
+                    sh.last_aniso[0] = o.aniso[0]; sh.last_aniso[1] = o.aniso[1]; sh.last_aniso[2] = o.aniso[2];
+                    medium_state st;
+                    state_from_ray(&sh, &st);
+                    cnt->n_seg++;
+                    int vis = transmittance_one(m, cnt, &sh, &st);
+                    emission += throughput * (f * (vis ? 1.f : 0.f) * s->light_radiance);
+                }
+            }
+        }
+        /* phase sample (LambertBsdf::sample): fails when the ray arrives from below the surface */
+        if (!(wi.z > 0.0f))
+            break;
+        float dx, dy, d2;
+        do {
+            dx = 2.f * pcg_next_1d(&g) - 1.f;
+            dy = 2.f * pcg_next_1d(&g) - 1.f;
+            d2 = dx * dx + dy * dy;
+        } while (!(d2 < 1.f));
+        float rem = 1.0f - d2;
+        v3f wo_l = v3(dx, dy, sqrtf(rem > 0.f ? rem : 0.f));
+        v3f w = v3_normalized(frame_to_global(&fr, wo_l));
+        throughput *= albedo;
+        /* ray = ray.scatter(p, w, 0); state advanced by sampleDistance (GPM.cpp:329-338) */
+        float t0, t1;
+        if (!sphere_chord(p, w, s->bound_radius, &t0, &t1))
+            break;
+        gpis_ray_in next;
+        memset(&next, 0, sizeof next);
+        next.pos[0] = p.x; next.pos[1] = p.y; next.pos[2] = p.z;
+        next.dir[0] = w.x; next.dir[1] = w.y; next.dir[2] = w.z;
+        next.near_t = 0.f; next.far_t = t1;
+        next.pixel[0] = px; next.pixel[1] = py; next.spp = spp;
+        next.scene_seed = s->scene_seed;
+        next.info_t = ray.info_t + o.sample_t;
+        next.first_scatter = 0;
+        next.bounce = ray.bounce + 1;
+        next.last_val = o.last_val;
+        next.last_gp_id = o.gp_id;
+        next.last_aniso[0] = o.aniso[0]; next.last_aniso[1] = o.aniso[1]; next.last_aniso[2] = o.aniso[2];
+        ray = next;
+    }
+    return emission;
+}
+
+typedef struct { const gpis_scene_s *s; float *rad; int max_bounces; float albedo; } paths_ctx;
+static void paths_range(oracle_medium *m, oracle_counters *cnt, size_t i0, size_t i1, void *c)
+{
+    paths_ctx *x = (paths_ctx *)c;
+    const gpis_scene_s *s = x->s;
+    for (size_t idx = i0; idx < i1; ++idx) {
+        uint32_t py = s->y_begin + (uint32_t)(idx / s->width), px = (uint32_t)(idx % s->width);
+        float acc = 0.f;
+        for (uint32_t k = 0; k < s->spp_count; ++k)
+            acc += scene_paths_sample(m, cnt, s, px, py, s->spp_begin + k, x->max_bounces, x->albedo);
+        x->rad[(size_t)py * s->width + px] += acc;
+    }
+}
+int oracle_render_scene_s_paths(oracle_medium *m, const gpis_scene_s *s, int max_path_bounces, float albedo, float *radiance_sum)
+{
+    if (!m || !s || !radiance_sum || max_path_bounces < 1) return fail("bad argument");
+    if (s->y_begin + s->y_count > s->height) return fail("row range outside the image");
+    paths_ctx c = {s, radiance_sum, max_path_bounces, albedo};
+    parallel_for(m, (size_t)s->y_count * s->width, paths_range, &c);
+    return GPIS_OK;
+}
+
 /* ======================================================================================
  * Pinning surface
  * ==================================================================================== */

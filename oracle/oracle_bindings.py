@@ -58,6 +58,7 @@ class Oracle:
         L.oracle_reset_counters.argtypes = [_vp]
         L.oracle_render_scene_s.argtypes = [_vp, _vp, _vp, _vp]
         L.oracle_scene_s_primary.argtypes = [_vp, _u32, _u32, _u32, _vp, _vp]
+        L.oracle_render_scene_s_paths.argtypes = [_vp, _vp, _i32, _f32, _vp]
         self.params = np.array(params, dtype=PARAMS)
         h = _vp()
         st = L.oracle_create(_p(self.params), ctypes.byref(h))
@@ -142,6 +143,12 @@ class Oracle:
         hits = np.zeros_like(rad, dtype=np.uint32) if want_hits else None
         assert self.lib.oracle_render_scene_s(self.h, _p(scene), _p(rad), _p(hits)) == 0
         return (rad, hits) if want_hits else rad
+
+    def render_scene_s_paths(self, scene, max_bounces, albedo):
+        scene = np.array(scene, dtype=SCENE_S)
+        rad = np.zeros((int(scene["height"]), int(scene["width"])), dtype=np.float32)
+        assert self.lib.oracle_render_scene_s_paths(self.h, _p(scene), int(max_bounces), _f32(albedo), _p(rad)) == 0
+        return rad
 
     def scene_s_primary(self, scene, x, y, spp):
         scene = np.array(scene, dtype=SCENE_S)

@@ -197,7 +197,7 @@ class GpisLib:
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
         "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck",
-        "gpis_default_scene_s", "gpis_render_scene_s",
+        "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths",
     ]
 
     def __init__(self, path=None):
@@ -251,6 +251,7 @@ class GpisLib:
         L.gpis_default_scene_s.argtypes = [vp, u32, u32, u32]
         L.gpis_default_scene_s.restype = None
         L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
+        L.gpis_render_scene_s_paths.argtypes = [vp, vp, i32, ctypes.c_float, vp, vp]
         if hasattr(L, "gpis_abi_sizes"):
             L.gpis_abi_sizes.restype = ctypes.c_char_p
             got = dict(kv.split("=") for kv in L.gpis_abi_sizes().decode().split(","))

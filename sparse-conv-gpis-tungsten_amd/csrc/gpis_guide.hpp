@@ -46,7 +46,10 @@ struct GuideField {
     int enabled;
 };
 
-constexpr int kSoloMaxLanes = 3;            // clusters up to this size use the sideways evaluator
+#ifndef GPIS_SOLO_MAX
+#define GPIS_SOLO_MAX 3
+#endif
+constexpr int kSoloMaxLanes = GPIS_SOLO_MAX;   // clusters up to this size use the sideways evaluator
 constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the block's cells an impulse contributes exactly 0
 
 // one wave = one 4x4x4 block of grid points

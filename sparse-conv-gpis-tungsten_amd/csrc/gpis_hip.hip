@@ -529,6 +529,152 @@ __global__ void __launch_bounds__(256) k_scene_accumulate(SceneConst sc, size_t 
     if (hit_count) hit_count[first_pixel + j] += hits;
 }
 
+
+// --------------------------------------------------------------------------------------
+// multi-bounce wavefront driver (gpis_render_scene_s_paths): PathTracer.cpp:62-75,
+// TraceBase.cpp:346-386 and 539-563 with a Lambertian micro-surface (BRDFPhaseFunction.cpp:27-96,
+// LambertBsdf.cpp:27-47) and a directional (Dirac) light.  Path state lives in SoA arrays; the
+// medium kernels are the same batch entries a host integrator would call.
+// --------------------------------------------------------------------------------------
+struct PathArrays {
+    gpis_ray_in *rays;       // current segment of every path (rewritten in place at each bounce)
+    gpis_seg_out *seg;
+    gpis_ray_in *shadow;
+    uint64_t *rng;           // PCG32 state of the sample's stream
+    float *throughput, *emission, *contrib;
+    uint8_t *alive, *nee, *vis;
+};
+
+__global__ void __launch_bounds__(256) k_paths_begin(SceneConst sc, size_t first_pixel, size_t n_samples, PathArrays a)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    const gpis_scene_s &s = sc.s;
+    size_t pix = first_pixel + i / s.spp_count;
+    uint32_t k = (uint32_t)(i % s.spp_count);
+    uint32_t x = (uint32_t)(pix % s.width), y = (uint32_t)(pix / s.width);
+    uint32_t spp = s.spp_begin + k;
+    Pcg32 g;
+    g.set_state((uint64_t)(uint32_t)(xxhash32_4(x, y, spp, s.scene_seed) + 1u));
+    float jx = normalized_uint(g.next_i()), jy = normalized_uint(g.next_i());
+    float u0 = normalized_uint(g.next_i());
+    V3 local = normalized(v3(-1.0f + ((float)x + jx) * 2.0f * sc.psx, sc.ratio - ((float)y + jy) * 2.0f * sc.psx, sc.plane_dist));
+    V3 d = v3(local.x, local.y, -local.z);
+    V3 o = v3(s.cam_pos[0], s.cam_pos[1], s.cam_pos[2]);
+    gpis_ray_in r;
+    memset(&r, 0, sizeof r);
+    r.pos[0] = o.x; r.pos[1] = o.y; r.pos[2] = o.z;
+    r.dir[0] = d.x; r.dir[1] = d.y; r.dir[2] = d.z;
+    r.pixel[0] = x; r.pixel[1] = y; r.spp = spp; r.segment = 0;
+    r.scene_seed = s.scene_seed; r.info_t = 0.f; r.u_jitter = u0;
+    r.first_scatter = 1;
+    float t0 = 0.f, t1 = 0.f;
+    bool hit = sphere_chord(o, d, s.bound_radius, t0, t1);
+    r.near_t = t0; r.far_t = t1;
+    a.rays[i] = r;
+    a.rng[i] = g.state;
+    a.throughput[i] = 1.f;
+    a.emission[i] = 0.f;
+    a.alive[i] = hit ? 1 : 0;
+}
+
+// after sampleDistance of segment `bounce`: next-event estimation set-up + the bounce itself
+__global__ void __launch_bounds__(256) k_paths_shade(SceneConst sc, size_t n_samples, int bounce, int max_bounces, float albedo, PathArrays a)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    uint8_t nee = 0;
+    if (!a.alive[i]) { a.nee[i] = 0; return; }
+    const gpis_seg_out o = a.seg[i];
+    if (!o.ok) { a.alive[i] = 0; a.nee[i] = 0; return; }
+    float thr = a.throughput[i] * o.weight[0];
+    if (o.exited) { a.alive[i] = 0; a.nee[i] = 0; a.throughput[i] = thr; return; }
+    const gpis_ray_in ray = a.rays[i];
+    Pcg32 g;
+    g.state = a.rng[i];
+    const V3 l = v3(sc.light[0], sc.light[1], sc.light[2]);
+    const double ax = o.aniso[0], ay = o.aniso[1], az = o.aniso[2];
+    const double len = sqrt(ax * ax + ay * ay + az * az);
+    const V3 n = v3((float)(ax / len), (float)(ay / len), (float)(az / len));
+    const Frame fr = frame_from_normal(n);
+    const V3 dir = v3(ray.dir[0], ray.dir[1], ray.dir[2]);
+    const V3 wi = normalized(to_local(fr, v3(-dir.x, -dir.y, -dir.z)));
+    const V3 p = v3(o.p[0], o.p[1], o.p[2]);
+    gpis_ray_in next;
+    memset(&next, 0, sizeof next);
+    next.pos[0] = p.x; next.pos[1] = p.y; next.pos[2] = p.z;
+    next.near_t = 0.f;
+    next.pixel[0] = ray.pixel[0]; next.pixel[1] = ray.pixel[1]; next.spp = ray.spp;
+    next.scene_seed = ray.scene_seed;
+    next.info_t = ray.info_t + o.sample_t;
+    next.first_scatter = 0;
+    next.bounce = ray.bounce + 1;
+    next.last_val = o.last_val;
+    next.last_gp_id = o.gp_id;
+    next.last_aniso[0] = o.aniso[0]; next.last_aniso[1] = o.aniso[1]; next.last_aniso[2] = o.aniso[2];
+    if (bounce < max_bounces - 1) {
+        const V3 wo = normalized(to_local(fr, l));
+        if (wi.z > 0.0f && wo.z > 0.0f) {
+            const float f = albedo * (1.0f / 3.1415926536f) * wo.z;
+            float t0, t1;
+            if (sphere_chord(p, l, sc.s.bound_radius, t0, t1)) {
+                gpis_ray_in sh = next;
+                sh.dir[0] = l.x; sh.dir[1] = l.y; sh.dir[2] = l.z;
+                sh.far_t = t1;
+                sh.segment = (uint32_t)bounce + 1;
+                sh.u_jitter = normalized_uint(g.next_i());
+                a.shadow[i] = sh;
+                a.contrib[i] = thr * (f * sc.s.light_radiance);
+                nee = 1;
+            }
+        }
+    }
+    a.nee[i] = nee;
+    bool alive = wi.z > 0.0f;
+    if (alive) {
+        float dx, dy, d2;
+        do {
+            dx = 2.f * normalized_uint(g.next_i()) - 1.f;
+            dy = 2.f * normalized_uint(g.next_i()) - 1.f;
+            d2 = dx * dx + dy * dy;
+        } while (!(d2 < 1.f));
+        const float rem = 1.0f - d2;
+        const V3 w = normalized(to_global(fr, v3(dx, dy, sqrtf(rem > 0.f ? rem : 0.f))));
+        thr *= albedo;
+        float t0, t1;
+        alive = sphere_chord(p, w, sc.s.bound_radius, t0, t1);
+        if (alive) {
+            next.dir[0] = w.x; next.dir[1] = w.y; next.dir[2] = w.z;
+            next.far_t = t1;
+            next.segment = (uint32_t)bounce + 1;
+            next.u_jitter = normalized_uint(g.next_i());
+            a.rays[i] = next;
+        }
+    }
+    a.alive[i] = alive ? 1 : 0;
+    a.throughput[i] = thr;
+    a.rng[i] = g.state;
+}
+
+__global__ void __launch_bounds__(256) k_paths_nee_add(size_t n_samples, PathArrays a)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    if (a.nee[i])
+        a.emission[i] += a.vis[i] ? a.contrib[i] : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_paths_accumulate(uint32_t spp, size_t first_pixel, size_t n_pixels, const float *__restrict__ emission,
+                                                          float *__restrict__ radiance_sum)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pixels) return;
+    float acc = 0.f;
+    for (uint32_t k = 0; k < spp; ++k)
+        acc += emission[j * spp + k];
+    radiance_sum[first_pixel + j] += acc;
+}
+
 // ======================================================================================
 // C ABI
 // ======================================================================================
@@ -1039,13 +1185,8 @@ extern "C" void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t h
     s->y_begin = 0; s->y_count = height;
 }
 
-extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum, uint32_t *hit_count, void *stream)
+static SceneConst make_scene_const(const gpis_scene_s *s)
 {
-    CHECK_ARGS(m && s && radiance_sum);
-    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
-    std::lock_guard<std::mutex> lock(m->mu);
-    HIP_TRY(hipSetDevice(m->device));
-    hipStream_t st = (hipStream_t)stream;
     SceneConst sc;
     sc.s = *s;
     const float pi_f = 3.1415926536f;
@@ -1059,6 +1200,17 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
         float inv = 1.0f / sqrtf(l2);
         sc.light[0] = lx * inv; sc.light[1] = ly * inv; sc.light[2] = lz * inv;
     }
+    return sc;
+}
+
+extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum, uint32_t *hit_count, void *stream)
+{
+    CHECK_ARGS(m && s && radiance_sum);
+    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    SceneConst sc = make_scene_const(s);
     const size_t total_pixels = (size_t)s->y_count * s->width;
     const size_t first_pixel0 = (size_t)s->y_begin * s->width;
     const size_t target_samples = (size_t)1 << 23;   // ~8 Mi samples (≈3 GB of workspace) per chunk
@@ -1090,6 +1242,54 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
         if ((rc = transmittance_impl(m, ns, sh, vis, v2, st))) return rc;
         k_scene_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, first_pixel0 + p0, np, cosl, v2, vis, hit, radiance_sum, hit_count);
         if ((rc = launch_check("k_scene_accumulate"))) return rc;
+    }
+    return GPIS_OK;
+}
+
+extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, int max_path_bounces, float albedo, float *radiance_sum, void *stream)
+{
+    CHECK_ARGS(m && s && radiance_sum && max_path_bounces >= 1);
+    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    SceneConst sc = make_scene_const(s);
+    const size_t total_pixels = (size_t)s->y_count * s->width;
+    const size_t first_pixel0 = (size_t)s->y_begin * s->width;
+    size_t chunk_pixels = ((size_t)1 << 23) / s->spp_count;
+    if (chunk_pixels < 1) chunk_pixels = 1;
+    if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
+    const size_t ns_max = chunk_pixels * s->spp_count;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_rays = carve(ns_max * sizeof(gpis_ray_in)), o_seg = carve(ns_max * sizeof(gpis_seg_out)), o_sh = carve(ns_max * sizeof(gpis_ray_in));
+    size_t o_rng = carve(ns_max * 8), o_thr = carve(ns_max * 4), o_em = carve(ns_max * 4), o_con = carve(ns_max * 4);
+    size_t o_alive = carve(ns_max), o_nee = carve(ns_max), o_vis = carve(ns_max);
+    int rc = ensure_stage(m, 3, off);
+    if (rc) return rc;
+    char *ws = (char *)m->stage[3];
+    PathArrays a;
+    a.rays = (gpis_ray_in *)(ws + o_rays); a.seg = (gpis_seg_out *)(ws + o_seg); a.shadow = (gpis_ray_in *)(ws + o_sh);
+    a.rng = (uint64_t *)(ws + o_rng);
+    a.throughput = (float *)(ws + o_thr); a.emission = (float *)(ws + o_em); a.contrib = (float *)(ws + o_con);
+    a.alive = (uint8_t *)(ws + o_alive); a.nee = (uint8_t *)(ws + o_nee); a.vis = (uint8_t *)(ws + o_vis);
+    for (size_t p0 = 0; p0 < total_pixels; p0 += chunk_pixels) {
+        size_t np = total_pixels - p0 < chunk_pixels ? total_pixels - p0 : chunk_pixels;
+        size_t ns = np * s->spp_count;
+        k_paths_begin<<<grid_of(ns, 256), 256, 0, st>>>(sc, first_pixel0 + p0, ns, a);
+        if ((rc = launch_check("k_paths_begin"))) return rc;
+        // the segment of bounce max-1 cannot contribute (no NEE there, TraceBase.cpp:546, and the
+        // light is a Dirac delta), so it is not traced
+        for (int bounce = 0; bounce + 1 < max_path_bounces; ++bounce) {
+            if ((rc = sample_distance_impl(m, ns, a.rays, a.seg, nullptr, a.alive, st))) return rc;
+            k_paths_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, ns, bounce, max_path_bounces, albedo, a);
+            if ((rc = launch_check("k_paths_shade"))) return rc;
+            if ((rc = transmittance_impl(m, ns, a.shadow, a.vis, a.nee, st))) return rc;
+            k_paths_nee_add<<<grid_of(ns, 256), 256, 0, st>>>(ns, a);
+            if ((rc = launch_check("k_paths_nee_add"))) return rc;
+        }
+        k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(s->spp_count, first_pixel0 + p0, np, a.emission, radiance_sum);
+        if ((rc = launch_check("k_paths_accumulate"))) return rc;
     }
     return GPIS_OK;
 }

@@ -123,7 +123,9 @@ def oracle_vectors():
     # the C0 scene-S image: 64x64, 4 spp — radiance sums and per-pixel hit counts
     orc = ob.Oracle(pkg.params_for_config("C0"), threads=8)
     rad, hits = orc.render_scene_s(ob.default_scene_s(64, 64, 4), want_hits=True)
-    np.savez_compressed(os.path.join(HERE, "oracle_C0_image64.npz"), radiance_sum=rad, hits=hits)
+    # the same scene through the multi-bounce driver: 4 path bounces, albedo 0.8
+    paths = orc.render_scene_s_paths(ob.default_scene_s(64, 64, 4), 4, 0.8)
+    np.savez_compressed(os.path.join(HERE, "oracle_C0_image64.npz"), radiance_sum=rad, hits=hits, paths_radiance_sum=paths)
 
 
 def reference_kat():

@@ -84,3 +84,5 @@ def test_oracle_image_fixture(pkg, ob):
     orc = ob.Oracle(pkg.params_for_config("C0"), threads=8)
     rad, hits = orc.render_scene_s(ob.default_scene_s(64, 64, 4), want_hits=True)
     assert np.array_equal(rad, g["radiance_sum"]) and np.array_equal(hits, g["hits"])
+    paths = orc.render_scene_s_paths(ob.default_scene_s(64, 64, 4), 4, 0.8)
+    assert np.array_equal(paths, g["paths_radiance_sum"]) and paths.sum() > 0

@@ -66,3 +66,7 @@ def test_gpu_image_fixture(pkg):
     torch.cuda.synchronize()
     assert np.array_equal(rad.cpu().numpy().reshape(64, 64), g["radiance_sum"])
     assert np.array_equal(hits.cpu().numpy().reshape(64, 64).astype(np.uint32), g["hits"])
+    rad.zero_()
+    med.call("gpis_render_scene_s_paths", scene.ctypes.data_as(ctypes.c_void_p), 4, 0.8, rad.data_ptr(), stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(rad.cpu().numpy().reshape(64, 64), g["paths_radiance_sum"])

@@ -459,6 +459,34 @@ def test_render_scene_s_small(env, path):
         assert np.array_equal(rad2.cpu().numpy().reshape(h, w), want)
 
 
+@pytest.mark.parametrize("path", ["guided_coarse", "fast", "generic"])
+def test_render_scene_s_paths(env, path):
+    """Multi-bounce wavefront driver (TraceBase::handleVolume semantics): bit-exact image against the
+    oracle's per-sample recursion, including incoherent secondary segments and shadow rays."""
+    import torch
+    pkg, ob, lib = env
+    for cfg, (w, h, spp), bounces in (("C0", (64, 64, 4), 4), ("C1", (64, 36, 8), 3)):
+        params = pkg.params_for_config(cfg)
+        med, orc = _medium(pkg, params, path), ob.Oracle(params, threads=16)
+        scene = ob.default_scene_s(w, h, spp)
+        want = orc.render_scene_s_paths(scene, bounces, 0.8)
+        single = orc.render_scene_s_paths(scene, 2, 0.8)
+        rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+        sc = np.array(scene, dtype=pkg.SCENE_S)
+        med.call("gpis_render_scene_s_paths", sc.ctypes.data_as(ctypes.c_void_p), bounces, 0.8, rad.data_ptr(), stream_ptr())
+        torch.cuda.synchronize()
+        got = rad.cpu().numpy().reshape(h, w)
+        assert np.array_equal(got, want), (cfg, np.abs(got - want).max())
+        # more bounces only add light
+        assert (want >= single).all() and want.sum() > single.sum() > 0
+    # one bounce = no next-event estimation at all (TraceBase.cpp:546): a black image
+    rad.zero_()
+    med.call("gpis_render_scene_s_paths", sc.ctypes.data_as(ctypes.c_void_p), 1, 0.8, rad.data_ptr(), stream_ptr())
+    torch.cuda.synchronize()
+    assert float(rad.abs().sum()) == 0.0
+    assert med.L.lib.gpis_render_scene_s_paths(med.h, sc.ctypes.data_as(ctypes.c_void_p), 0, 0.8, rad.data_ptr(), None) == -1
+
+
 def test_error_behaviour(env):
     pkg, ob, lib = env
     bad = pkg.params_for_config("C0")

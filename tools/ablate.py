@@ -7,8 +7,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     import _gpis_pkg, torch
     pkg = _gpis_pkg.load_package()
     lib = pkg.GpisLib(sys.argv[2])
-    w, h, spp = 480, 270, 64
+    w, h, spp = 960, 540, 64
     med = pkg.Medium(pkg.params_for_config("C1"), lib=lib)
+    if os.environ.get("ABLATE_GUIDE", "16:32") != "off":
+        gh, gp = (int(x) for x in os.environ.get("ABLATE_GUIDE", "16:32").split(":"))
+        med.build_guide(gh, gp)
     scene = np.zeros((), dtype=pkg.SCENE_S)
     lib.lib.gpis_default_scene_s(scene.ctypes.data, w, h, spp)
     rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
