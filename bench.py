@@ -181,6 +181,12 @@ def main():
         ms, launches, n_eval, n_seg = prof[dom]
         bytes_alg = n_eval * b_eval + n_seg * B_SEG
         achieved = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # the same figure priced at the evaluations the REFERENCE algorithm performs on these segments:
+        # every march step the guide certified stands for one evaluateValue of GPM.cpp:189-193
+        n_eval_all = prof[0][2] + prof[1][2] + n_guide
+        n_seg_all = prof[0][3] + prof[1][3]
+        ms_all = prof[0][0] + prof[1][0]
+        ref_equiv = (n_eval_all * b_eval + n_seg_all * B_SEG) / (ms_all * 1e-3) / 1e9 if ms_all > 0 else 0.0
         fast = int(med.derived()["fast_path"])
         kernel = ("k_guided_" if guide_info else ("k_fast_" if fast else "k_")) + names[dom]
         res = {
@@ -203,6 +209,8 @@ def main():
                 "bytes_per_eval": b_eval, "bytes_per_segment": B_SEG, "n_eval": n_eval, "n_seg": n_seg,
                 "evals_per_s": (prof[0][2] + prof[1][2]) / dt_max,
                 "guide_lookups": n_guide, "guide_lookups_per_s": n_guide / dt_max,
+                "reference_equivalent": {"evals": n_eval_all, "segments": n_seg_all, "GBps": ref_equiv,
+                                         "doc": "both medium kernels, counting a certified march step as the evaluation it replaces"},
                 "kernel_ms": {names[0]: prof[0][0], names[1]: prof[1][0]},
                 "note": "impulses are generated or gathered on chip; the binding roof is VALU integer/fp32 issue, "
                         "the HBM figure uses SURVEY.md 8d's algorithmic-bytes definition",
