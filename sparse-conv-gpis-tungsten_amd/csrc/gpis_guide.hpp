@@ -46,6 +46,12 @@ struct GuideField {
     int enabled;
 };
 
+#ifndef GPIS_GUIDE_OCC
+// waves per SIMD the guided kernels are register-allocated for.  Guide lookups are latency-bound, so
+// occupancy beats spill-free code here: measured on C1 960x540x64 (sd+tr ms) occ2 180 (no spills),
+// occ3 149, occ4 137, occ5 146, occ6 154, occ8 183
+#define GPIS_GUIDE_OCC 4
+#endif
 #ifndef GPIS_SOLO_MAX
 #define GPIS_SOLO_MAX 3
 #endif
@@ -446,7 +452,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
 
 struct GuideCounters { unsigned long long n_guide; };
 
-__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_guided_sample_distance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_distance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
                                                                                      const gpis_ray_in *__restrict__ rays, gpis_seg_out *__restrict__ out,
                                                                                      gpis_cond_coeff *__restrict__ coeff, const uint8_t *__restrict__ mask,
                                                                                      Counters *cnt, unsigned long long *guide_cnt)
@@ -470,7 +476,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_guided_sample_dis
     if ((threadIdx.x & 63) == 0 && gsum) atomicAdd(guide_cnt, gsum);
 }
 
-__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
                                                                                    const gpis_ray_in *__restrict__ rays, uint8_t *__restrict__ visible,
                                                                                    const uint8_t *__restrict__ mask, Counters *cnt, unsigned long long *guide_cnt)
 {
