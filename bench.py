@@ -208,7 +208,7 @@ def main():
                 "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                 "bytes_per_eval": b_eval, "bytes_per_segment": B_SEG, "n_eval": n_eval, "n_seg": n_seg,
                 "evals_per_s": (prof[0][2] + prof[1][2]) / dt_max,
-                "guide_lookups": n_guide, "guide_lookups_per_s": n_guide / dt_max,
+                "certified_steps": n_guide, "certified_steps_per_s": n_guide / dt_max,
                 "reference_equivalent": {"evals": n_eval_all, "segments": n_seg_all, "GBps": ref_equiv,
                                          "doc": "both medium kernels, counting a certified march step as the evaluation it replaces"},
                 "kernel_ms": {names[0]: prof[0][0], names[1]: prof[1][0]},

@@ -319,7 +319,8 @@ int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_
  * the wave-cooperative path does not cover.  gpis_drop_guide frees it. */
 int gpis_build_guide(gpis_medium *m, int half_extent_cells, int points_per_cell);
 int gpis_drop_guide(gpis_medium *m);
-/* Guide lookups performed since the last gpis_reset_counters (exact evaluations stay in n_eval). */
+/* March steps certified by the guide since the last gpis_reset_counters: each stands for one
+ * evaluateValue call of the reference (exact evaluations stay in n_eval). */
 int gpis_get_guide_steps(gpis_medium *m, uint64_t *n_guide);
 /* Test surface: evaluates the exact lattice sum and the guide at n grid-space points (device
  * pointer, xyz triples; consecutive groups of 64 must lie within one cell of each other) and reports

@@ -146,10 +146,12 @@ GPIS_DEV float wave_max_f(float v)
 #endif
 #define GPIS_KEEP(x) asm volatile("" ::"v"(x))
 #ifdef GPIS_FAST_STATS
-__device__ unsigned long long g_fast_stats[16];
+__device__ unsigned long long g_fast_stats[32];
 #define FSTAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fast_stats[i], (unsigned long long)(v)); } while (0)
+#define FCLK() ((long long)__builtin_readcyclecounter())
 #else
 #define FSTAT(i, v) do { } while (0)
+#define FCLK() 0LL
 #endif
 
 constexpr int kFastBlock = 64;          // one wave per workgroup

@@ -298,21 +298,26 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         phase = X_REFINE;
     };
 
+    long long clk_a = 0, clk_b = 0;      // diagnostic builds only (GPIS_FAST_STATS)
     for (;;) {
         // ---- A: guide steps for every lane that can take one ----
+        const long long clk_a0 = FCLK();
         for (;;) {
             if (!WANT_SAMPLE && phase == X_FINAL) {
                 hit = false;                // transmittance: the segment exits, lastVal is not part of the result
                 phase = G_DONE;
             }
             const bool stepping = phase == G_INIT || phase == G_MARCH;
-            if (__ballot(stepping) == 0ULL)
+            const unsigned long long step_mask = __ballot(stepping);
+            if (step_mask == 0ULL)
                 break;
+            FSTAT(20, 1);
+            FSTAT(21, __popcll(step_mask));
             if (stepping) {
-                n_guide++;
                 if (phase == G_INIT) {
                     const int s = guide_sign(M, F, world_at((double)nearT), coord);
                     if (s != 0) {
+                        n_guide++;          // counts certified steps: each stands for one evaluateValue of the reference
                         sign0 = s;
                         pf_valid = false;
                         begin_march();
@@ -323,6 +328,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
                     const int s = guide_sign(M, F, world_at(t), coord);
                     const bool adopt = !first_scatter && step == 0;   // the reference's `step == 1` after step++ (SCNM.cpp:138-140)
                     if (s != 0 && (adopt || s == sign0)) {
+                        n_guide++;
                         step++;
                         if (adopt) sign0 = s;
                         pf_valid = false;
@@ -333,7 +339,9 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
                 }
             }
         }
+        clk_a += FCLK() - clk_a0;
         // ---- B: exact evaluations for the parked lanes, one coherent cluster at a time ----
+        const long long clk_b0 = FCLK();
         const bool need = phase >= X_F0 && phase <= X_FINAL;
         const unsigned long long need_mask = __ballot(need);
         if (need_mask == 0ULL)
@@ -349,8 +357,12 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         int gp_new;
         float fv;
         const unsigned long long cl_mask = __ballot(in_cluster);
+        FSTAT(22, 1);
+        FSTAT(23, __popcll(need_mask));
         if (__popcll(cl_mask) <= kSoloMaxLanes) {
             // few requests: one sideways (lane = impulse) evaluation per requesting lane
+            FSTAT(24, 1);
+            FSTAT(25, __popcll(cl_mask));
             fv = 0.f;
             gp_new = 0;
             for (unsigned long long mm = cl_mask; mm; mm &= mm - 1ULL) {
@@ -416,12 +428,17 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
                 phase = G_GRAD;
             }
         }
+        clk_b += FCLK() - clk_b0;
     }
+    FSTAT(16, clk_a);
+    FSTAT(17, clk_b);
+    FSTAT(18, clk_a + clk_b);
     visible = valid && !hit;
     if (!WANT_SAMPLE)
         return;
 
     // one gradient evaluation per segment (GPM.cpp:283 / 319), clustered like the value requests
+    const long long clk_g0 = FCLK();
     const bool want_grad = phase == G_GRAD;
     V3 g = v3(0.f, 0.f, 0.f);
     {
@@ -445,6 +462,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
             }
         }
     }
+    FSTAT(19, FCLK() - clk_g0);
     if (!valid)
         return;
     finish_sample_distance(M, rayp, pos, dir, farT, early_ok, want_grad, hit, t, last_val, gp, g, out);

@@ -1157,12 +1157,12 @@ extern "C" int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_
 
 #ifdef GPIS_FAST_STATS
 // diagnostic build only: read and clear the cooperative loop's work counters
-extern "C" int gpis_debug_fast_stats(uint64_t *out16)
+extern "C" int gpis_debug_fast_stats(uint64_t *out32)
 {
-    unsigned long long h[16];
+    unsigned long long h[32];
     if (hipDeviceSynchronize() != hipSuccess) return GPIS_ERR_DEVICE;
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gpis::g_fast_stats), sizeof h) != hipSuccess) return GPIS_ERR_DEVICE;
-    for (int i = 0; i < 16; ++i) out16[i] = h[i];
+    for (int i = 0; i < 32; ++i) out32[i] = h[i];
     memset(h, 0, sizeof h);
     if (hipMemcpyToSymbol(HIP_SYMBOL(gpis::g_fast_stats), h, sizeof h) != hipSuccess) return GPIS_ERR_DEVICE;
     return GPIS_OK;

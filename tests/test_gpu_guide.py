@@ -54,8 +54,11 @@ def test_guided_march_matches_oracle_and_saves_evaluations(pkg, ob):
         assert np.array_equal(got[f], want[f], equal_nan=True), f
         assert np.array_equal(got[f], base[f], equal_nan=True), f
     assert np.array_equal(med.transmittance(sh), vis_o)
-    print("exact evaluations: %d unguided, %d guided (+%d guide lookups) for %d segments" % (e_exact, e_guided, n_guide, len(rays)))
+    print("exact evaluations: %d unguided, %d guided (+%d certified steps) for %d segments" % (e_exact, e_guided, n_guide, len(rays)))
     assert e_guided < 0.35 * e_exact
+    # every evaluation of the exact march is either certified or performed; the only extra work is the
+    # one re-evaluation of a certified previous step when a crossing is refined (at most one per segment)
+    assert 0 <= e_guided + n_guide - e_exact <= len(rays)
     med.drop_guide()
     again = med.sample_distance(rays)
     assert np.array_equal(again["t"], want["t"])

@@ -22,7 +22,7 @@ if len(sys.argv) > 5 and sys.argv[5] != "off":
 rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
 med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, None)
 torch.cuda.synchronize()
-out = (ctypes.c_uint64 * 16)()
+out = (ctypes.c_uint64 * 32)()
 lib.lib.gpis_debug_fast_stats(out)
 names = ["wave_evals", "active_lanes", "cells_visited", "cells_mine", "cells_cand", "candidates", "union_pass", "lane_pass", "incoherent",
          "lanes_1_2", "lanes_3_4", "lanes_5_8", "lanes_9_16", "lanes_17_32", "lanes_33_64"]
@@ -32,5 +32,11 @@ print(st)
 print("per wave-eval: active lanes %.1f, cells visited %.1f, processed %.1f, with candidates %.1f, candidates %.1f, bodies %.1f, "
       "lane-passes/body %.1f, incoherent %.4f" % (st["active_lanes"] / e, st["cells_visited"] / e, st["cells_mine"] / e, st["cells_cand"] / e,
                                                  st["candidates"] / e, st["union_pass"] / e, st["lane_pass"] / max(st["union_pass"], 1), st["incoherent"] / e))
+g = list(out)[16:26]
+if g[2]:
+    tot = g[2] + g[3]
+    print("guided kernels (wave cycles, both kernels): guide loop %.1f%%, exact values %.1f%%, gradient tail %.1f%%; "
+          "guide-loop iterations %d (%.1f lanes stepping), exact rounds %d (%.1f lanes parked), of which sideways %d (%.1f lanes)" % (
+          100.0 * g[0] / tot, 100.0 * g[1] / tot, 100.0 * g[3] / tot, g[4], g[5] / max(g[4], 1), g[6], g[7] / max(g[6], 1), g[8], g[9] / max(g[8], 1)))
 print("lane evals", med.counters(), "guide steps", med.guide_steps())
 print("active lanes per exact wave-eval: %.1f" % (med.counters()[0] / e))
