@@ -26,8 +26,9 @@ def build(force=False):
     """Compile the restatement (and, where /root/reference exists, oracle/_ref)."""
     if force or not os.path.exists(ORACLE_SO) or \
             os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "gpis_oracle.c")):
-        subprocess.check_call(["make", "-s", "-f", os.path.join(_HERE, "Makefile"), ORACLE_SO])
-    subprocess.check_call(["make", "-s", "-f", os.path.join(_HERE, "Makefile"), "ref"])
+        subprocess.check_call(["make", "-s", "-f", os.path.join(_HERE, "Makefile"), ORACLE_SO], stdout=sys.stderr)
+    # stdout belongs to the caller (bench.py prints exactly one JSON line there)
+    subprocess.check_call(["make", "-s", "-f", os.path.join(_HERE, "Makefile"), "ref"], stdout=sys.stderr)
 
 
 def _p(a):

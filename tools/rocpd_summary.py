@@ -16,4 +16,4 @@ else:
     rows = c.execute("select kernel_name, counter_name, count(distinct dispatch_id), sum(value) from counters_collection group by 1, 2 order by 1, 2").fetchall()
     print("kernel,counter,launches,total,per_launch")
     for n, cn, k, tot in rows:
-        print("%s,%s,%d,%.3f,%.3f" % (short(n), cn, k, tot, tot / k))
+        print('"%s",%s,%d,%.3f,%.3f' % (short(n), cn, k, tot, tot / k))
