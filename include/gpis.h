@@ -328,6 +328,12 @@ int gpis_get_guide_steps(gpis_medium *m, uint64_t *n_guide);
 int gpis_guide_selfcheck(gpis_medium *m, size_t n, const float *points3, uint64_t *checked,
                          uint64_t *violations, float *max_ratio, float *mean_bound, void *stream);
 
+/* Test surface for the march's certificate: for each ray (device pointer) the first `steps` march
+ * positions of SCNM.cpp:129-132 are classified by the guide, and every certified sign is compared with
+ * the sign of the exact evaluateValue at the same position; `violations` must be 0. */
+int gpis_guide_raycheck(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint32_t steps,
+                        uint64_t *certified, uint64_t *violations, void *stream);
+
 /* ---- tile → ray-batch driver (SURVEY.md §8d "Scene S", §8f-1) -------------------- */
 
 typedef struct gpis_scene_s {

@@ -196,7 +196,7 @@ class GpisLib:
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
-        "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck",
+        "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
         "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths",
     ]
 
@@ -248,6 +248,7 @@ class GpisLib:
         L.gpis_drop_guide.argtypes = [vp]
         L.gpis_get_guide_steps.argtypes = [vp, vp]
         L.gpis_guide_selfcheck.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
+        L.gpis_guide_raycheck.argtypes = [vp, sz, vp, u32, vp, vp, vp]
         L.gpis_default_scene_s.argtypes = [vp, u32, u32, u32]
         L.gpis_default_scene_s.restype = None
         L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
@@ -361,6 +362,13 @@ class Medium:
         self.L.check(self.L.lib.gpis_guide_selfcheck(self.h, int(n), ctypes.c_void_p(int(points3_dev_ptr)), ctypes.byref(c), ctypes.byref(v),
                                                      ctypes.byref(r), ctypes.byref(b), stream), "gpis_guide_selfcheck")
         return c.value, v.value, r.value, b.value
+
+    def guide_raycheck(self, rays_dev_ptr, n, steps, stream=None):
+        """(certified steps, violations) over the first `steps` march positions of n device-resident rays."""
+        c, v = ctypes.c_uint64(), ctypes.c_uint64()
+        self.L.check(self.L.lib.gpis_guide_raycheck(self.h, int(n), ctypes.c_void_p(int(rays_dev_ptr)), int(steps), ctypes.byref(c),
+                                                    ctypes.byref(v), stream), "gpis_guide_raycheck")
+        return c.value, v.value
 
     def set_profiling(self, on):
         self.L.check(self.L.lib.gpis_set_profiling(self.h, int(bool(on))), "gpis_set_profiling")

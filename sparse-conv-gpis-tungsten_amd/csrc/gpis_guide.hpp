@@ -145,11 +145,19 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
         F.err[((size_t)bx * bs + (size_t)by) * bs + (size_t)bz] = emax;
 }
 
+// G and the bound at index-space coordinates (tx, ty, tz) = (u + half) * ppc; false outside the
+// tabulated volume
+GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err);
+
 // G(u) and the bound for the cell containing u; false when u is outside the tabulated volume
 GPIS_DEV bool guide_lookup(const GuideField &F, V3 u, float &g, float &err)
 {
     const float s = (float)F.ppc, off = (float)F.half;
-    const float tx = (u.x + off) * s, ty = (u.y + off) * s, tz = (u.z + off) * s;
+    return guide_lookup_index(F, (u.x + off) * s, (u.y + off) * s, (u.z + off) * s, g, err);
+}
+
+GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err)
+{
     const float fx0 = floorf(tx), fy0 = floorf(ty), fz0 = floorf(tz);
     const float lim = (float)(F.side - 2);
     if (!(fx0 >= 0.f && fy0 >= 0.f && fz0 >= 0.f && fx0 <= lim && fy0 <= lim && fz0 <= lim))
@@ -235,6 +243,58 @@ GPIS_DEV int guide_sign(const DevModel &M, const GuideField &F, V3 p, const Fram
     return 0;
 }
 
+// The march visits p(t) = pos + t*dir, and the grid position is a LINEAR map of p (iso-ray space:
+// rotation into the ray frame of the whitened position; world space: p / R), so the index-space
+// coordinates of a step are a + t*b with a, b computed once per segment in double.  The lookup position
+// then differs from the fp32 position the exact evaluator derives for the same t by a few fp32 ulps of
+// |u| <= half (< 2e-5 cells), inside the 1e-4 position slack the stored bound carries (k_guide_build).
+struct GuideRay {
+    double ax, ay, az, bx, by, bz;   // index coordinates = a + t*b
+    float sn;                        // sigma / norm
+};
+
+GPIS_DEV GuideRay guide_ray(const DevModel &M, const GuideField &F, V3 pos, V3 dir, const Frame &coord)
+{
+    auto lin = [&](V3 v, double &x, double &y, double &z) {
+        double wx = (double)v.x, wy = (double)v.y, wz = (double)v.z;
+        if (M.iso3d) {
+            const float *m = M.w2l;    // stationary media only: cov_xf_scale == 1 (cov_pos_w2l)
+            const double lx = (double)GM(m, 0, 0) * wx + (double)GM(m, 0, 1) * wy + (double)GM(m, 0, 2) * wz;
+            const double ly = (double)GM(m, 1, 0) * wx + (double)GM(m, 1, 1) * wy + (double)GM(m, 1, 2) * wz;
+            const double lz = (double)GM(m, 2, 0) * wx + (double)GM(m, 2, 1) * wy + (double)GM(m, 2, 2) * wz;
+            wx = (double)coord.tangent.x * lx + (double)coord.tangent.y * ly + (double)coord.tangent.z * lz;
+            wy = (double)coord.bitangent.x * lx + (double)coord.bitangent.y * ly + (double)coord.bitangent.z * lz;
+            wz = (double)coord.normal.x * lx + (double)coord.normal.y * ly + (double)coord.normal.z * lz;
+        }
+        const double s = (double)F.ppc / (double)F.R;
+        x = wx * s; y = wy * s; z = wz * s;
+    };
+    GuideRay g;
+    lin(pos, g.ax, g.ay, g.az);
+    lin(dir, g.bx, g.by, g.bz);
+    const double off = (double)F.half * (double)F.ppc;
+    g.ax += off; g.ay += off; g.az += off;
+    g.sn = M.sigma / (M.iso3d ? M.norm3d_iso : M.norm3d_world);
+    return g;
+}
+
+// certified sign at march parameter t (world point p = pos + t*dir): +1 / -1, or 0 when undecided
+GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRay &gr, double t, V3 p)
+{
+    float g, err;
+    if (!guide_lookup_index(F, (float)(gr.ax + t * gr.bx), (float)(gr.ay + t * gr.by), (float)(gr.az + t * gr.bz), g, err))
+        return 0;
+    float ms;
+    const float mean = mean_approx(M, p, ms);
+    const float nv = g * gr.sn;
+    const float fa = nv + mean;
+    // 4e-6 relative also covers sigma*(g/norm) vs g*(sigma/norm) and the product roundings
+    const float margin = err * gr.sn * 1.0001f + ms + 4e-6f * (fabsf(nv) + fabsf(mean)) + 1e-7f;
+    if (fa > margin) return 1;
+    if (fa < -margin) return -1;
+    return 0;
+}
+
 template <bool WANT_SAMPLE>
 GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideField &F, FastLds &lds, bool valid,
                            const gpis_ray_in *__restrict__ rayp, gpis_seg_out *out, bool &visible, uint32_t &n_eval, uint32_t &n_guide)
@@ -259,6 +319,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
     if (M.iso3d)
         coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
 
+    const GuideRay gr = guide_ray(M, F, pos, dir, coord);
     int phase = G_INIT;
     bool early_ok = false;
     if (!valid)
@@ -297,6 +358,30 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         t_test = t_prev;
         phase = X_REFINE;
     };
+    // one trip of the shrink loop (SCNM.cpp:147-160).  It consumes only the SIGN of f(t_test), but asking
+    // the guide first does not pay: t_test lies inside the crossing step, i.e. inside the uncertainty band
+    // (measured on C1: 4 033 of 86.9 M trips certified)
+    auto refine_step = [&](int sign_test) {
+        bool done = false;
+        if (sign_test == sign0) {
+            done = true;
+        } else {
+            intp *= 0.9;
+            if (intp <= 0.01) {
+                t_prev = t_test = 0;
+                done = true;
+            } else {
+                t_prev = t_test;
+                t_test = lerp_d(a_lo, t, intp);
+            }
+        }
+        if (done) {
+            t = t_prev;
+            hit = true;
+            last_val = 0.0f;
+            phase = WANT_SAMPLE ? G_GRAD : G_DONE;
+        }
+    };
 
     long long clk_a = 0, clk_b = 0;      // diagnostic builds only (GPIS_FAST_STATS)
     for (;;) {
@@ -315,7 +400,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
             FSTAT(21, __popcll(step_mask));
             if (stepping) {
                 if (phase == G_INIT) {
-                    const int s = guide_sign(M, F, world_at((double)nearT), coord);
+                    const int s = guide_sign_at(M, F, gr, (double)nearT, world_at((double)nearT));
                     if (s != 0) {
                         n_guide++;          // counts certified steps: each stands for one evaluateValue of the reference
                         sign0 = s;
@@ -325,7 +410,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
                         phase = X_F0;
                     }
                 } else {
-                    const int s = guide_sign(M, F, world_at(t), coord);
+                    const int s = guide_sign_at(M, F, gr, t, world_at(t));
                     const bool adopt = !first_scatter && step == 0;   // the reference's `step == 1` after step++ (SCNM.cpp:138-140)
                     if (s != 0 && (adopt || s == sign0)) {
                         n_guide++;
@@ -374,6 +459,12 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         } else {
             fv = coop_evaluate_value(M, T, lds, in_cluster, pq, coord, gp_new, n_eval);
         }
+#ifdef GPIS_FAST_STATS
+        for (int ph = X_F0; ph <= X_FINAL; ++ph) {
+            const int served = __popcll(__ballot(in_cluster && phase == ph));
+            FSTAT(26 + ph - X_F0, served);
+        }
+#endif
         if (in_cluster) {
             gp = gp_new;
             const double f = (double)fv;
@@ -400,27 +491,8 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
             } else if (phase == X_PREV) {
                 pf = fv; pf_valid = true;
                 begin_refine();
-            } else if (phase == X_REFINE) {            // SCNM.cpp:147-160
-                const int sign_test = f < 0 ? -1 : 1;
-                bool done = false;
-                if (sign_test == sign0) {
-                    done = true;
-                } else {
-                    intp *= 0.9;
-                    if (intp <= 0.01) {
-                        t_prev = t_test = 0;
-                        done = true;
-                    } else {
-                        t_prev = t_test;
-                        t_test = lerp_d(a_lo, t, intp);
-                    }
-                }
-                if (done) {
-                    t = t_prev;
-                    hit = true;
-                    last_val = 0.0f;
-                    phase = WANT_SAMPLE ? G_GRAD : G_DONE;
-                }
+            } else if (phase == X_REFINE) {
+                refine_step(f < 0 ? -1 : 1);
             } else {                                   // X_FINAL: lastVal at farT (SCNM.cpp:176-181)
                 t = (double)farT;
                 last_val = fv;
@@ -555,6 +627,71 @@ __global__ void __launch_bounds__(kFastBlock) k_guide_selfcheck(const DevModel *
         atomicAdd(&stats[1], bad);
         atomicMax((unsigned int *)ratio_max, __float_as_uint(ratio));   // non-negative floats order like their bits
         atomicAdd(err_sum, es);
+    }
+}
+
+// Test surface for the march's certificate: walks the first `steps` march positions of every ray
+// (t = nearT + (k + u)*step, SCNM.cpp:129-132), and wherever the guide certifies a sign compares it
+// with the sign of the exact evaluateValue at the same t.  stats[0] = certified steps, stats[1] =
+// certified steps whose exact sign differs (must stay 0).
+__global__ void __launch_bounds__(kFastBlock) k_guide_raycheck(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+                                                              const gpis_ray_in *__restrict__ rays, uint32_t steps, unsigned long long *stats)
+{
+    __shared__ FastLds lds;
+    fast_lds_init(lds);
+    const DevModel &M = *Mp;
+    size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
+    const bool valid = i < n;
+    V3 pos = v3(0.f, 0.f, 1.f), dir = v3(0.f, 0.f, 1.f);
+    float nearT = 0.f, farT = 1.f, u = 0.f;
+    if (valid) {
+        pos = v3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
+        dir = v3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+        nearT = rays[i].near_t; farT = rays[i].far_t; u = rays[i].u_jitter;
+    }
+    float step_size = (farT - nearT) / (float)M.min_step;
+    if (M.step_size < step_size)
+        step_size = M.step_size;
+    Frame coord{};
+    if (M.iso3d)
+        coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
+    const GuideRay gr = guide_ray(M, F, pos, dir, coord);
+    double t = (double)(nearT + step_size * u);
+    unsigned long long certified = 0, bad = 0;
+    uint32_t n_eval = 0;
+    for (uint32_t k = 0; k < steps; ++k) {
+        const bool live = valid && t < (double)farT;
+        const V3 p = to_f(ray_at(to_d(pos), to_d(dir), t));
+        const int s = live ? guide_sign_at(M, F, gr, t, p) : 0;
+        // exact values for the lanes that hold a certificate, clustered like the march does
+        bool pending = s != 0;
+        const V3 ug = grid_point(M, F, p, coord);
+        const int cx = (int)floorf(ug.x), cy = (int)floorf(ug.y), cz = (int)floorf(ug.z);
+        for (;;) {
+            const unsigned long long pm = __ballot(pending);
+            if (pm == 0ULL)
+                break;
+            const int lead = __builtin_ctzll(pm);
+            const int ax0 = __builtin_amdgcn_readlane(cx, lead), ay0 = __builtin_amdgcn_readlane(cy, lead), az0 = __builtin_amdgcn_readlane(cz, lead);
+            const bool in_cluster = pending && cx >= ax0 && cx <= ax0 + 1 && cy >= ay0 && cy <= ay0 + 1 && cz >= az0 && cz <= az0 + 1;
+            int gp;
+            const float fv = coop_evaluate_value(M, T, lds, in_cluster, p, coord, gp, n_eval);
+            if (in_cluster) {
+                certified++;
+                if ((((double)fv < 0) ? -1 : 1) != s)
+                    bad++;
+                pending = false;
+            }
+        }
+        t += (double)step_size;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        certified += __shfl_down(certified, off, 64);
+        bad += __shfl_down(bad, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[0], certified);
+        atomicAdd(&stats[1], bad);
     }
 }
 

@@ -1128,6 +1128,26 @@ extern "C" int gpis_guide_selfcheck(gpis_medium *m, size_t n, const float *point
     return GPIS_OK;
 }
 
+extern "C" int gpis_guide_raycheck(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint32_t steps, uint64_t *certified,
+                                   uint64_t *violations, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || rays));
+    if (!m->guide.enabled) return set_err(GPIS_ERR_UNSUPPORTED, "gpis_guide_raycheck: no guide field built");
+    HIP_TRY(hipSetDevice(m->device));
+    unsigned long long *st = m->d_guide_cnt + 1;
+    HIP_TRY(hipMemsetAsync(st, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
+    if (n)
+        k_guide_raycheck<<<grid_of(n, kFastBlock), kFastBlock, 0, (hipStream_t)stream>>>(m->d_model, m->fast, m->guide, n, rays, steps, st);
+    int rc = launch_check("k_guide_raycheck");
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost));
+    if (certified) *certified = h[0];
+    if (violations) *violations = h[1];
+    return GPIS_OK;
+}
+
 extern "C" int gpis_set_profiling(gpis_medium *m, int enable)
 {
     CHECK_ARGS(m);

@@ -35,6 +35,36 @@ def test_guide_bound_holds(pkg, cfg, ppc):
     assert 0 < bound < 50
 
 
+@pytest.mark.parametrize("cfg,half,ppc", [("C1", 16, 32), ("C0", 16, 16), ("C1", 6, 8)])
+def test_certified_signs_agree_with_exact_values(pkg, ob, cfg, half, ppc):
+    """The certificate as the march uses it (index coordinates linear in t, fp32 mean, sigma/norm
+    folded): every certified sign along real camera and shadow rays equals the exact value's sign."""
+    params = pkg.params_for_config(cfg)
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    med.build_guide(half, ppc)
+    scene = ob.default_scene_s(320, 180, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    sh = shadow_rays_from(ob, scene, rays, us, orc.sample_distance(rays))
+    # a bundle far from the origin whose rays enter the tabulated volume late (large |a|, |t*b|)
+    rng = np.random.default_rng(11)
+    far = rays[:256].copy()
+    d = np.column_stack([rng.uniform(-0.02, 0.02, 256), rng.uniform(-0.02, 0.02, 256), np.ones(256)])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    far["pos"] = (44.0 * d).astype(np.float32)
+    aim = -d + rng.uniform(-0.004, 0.004, (256, 3))
+    far["dir"] = (aim / np.linalg.norm(aim, axis=1, keepdims=True)).astype(np.float32)
+    far["near_t"] = 42.5
+    far["far_t"] = 45.5
+    total = 0
+    for batch in (rays, sh, far):
+        d = to_dev(batch)
+        certified, bad = med.guide_raycheck(d.data_ptr(), len(batch), 400)
+        print("%s %d:%d: %d rays, %d certified steps, %d violations" % (cfg, half, ppc, len(batch), certified, bad))
+        assert bad == 0
+        total += certified
+    assert total > 50 * len(rays)
+
+
 def test_guided_march_matches_oracle_and_saves_evaluations(pkg, ob):
     params = pkg.params_for_config("C1")
     med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)

@@ -8,8 +8,12 @@ import _gpis_pkg
 pkg = _gpis_pkg.load_package()
 so = os.path.join(ROOT, "gpurun_out", "libgpis_hip_stats.so")
 csrc = os.path.join(ROOT, "sparse-conv-gpis-tungsten_amd", "csrc")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DGPIS_FAST_STATS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so, os.path.join(csrc, "gpis_hip.hip")])
+prebuilt = os.path.join(ROOT, "build", "stats", "libgpis_hip_stats.so")
+if os.path.exists(prebuilt):
+    so = prebuilt
+else:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                           "-DGPIS_FAST_STATS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so, os.path.join(csrc, "gpis_hip.hip")])
 import torch
 lib = pkg.GpisLib(so)
 w, h, spp = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (480, 270, 64)))
@@ -38,5 +42,9 @@ if g[2]:
     print("guided kernels (wave cycles, both kernels): guide loop %.1f%%, exact values %.1f%%, gradient tail %.1f%%; "
           "guide-loop iterations %d (%.1f lanes stepping), exact rounds %d (%.1f lanes parked), of which sideways %d (%.1f lanes)" % (
           100.0 * g[0] / tot, 100.0 * g[1] / tot, 100.0 * g[3] / tot, g[4], g[5] / max(g[4], 1), g[6], g[7] / max(g[6], 1), g[8], g[9] / max(g[8], 1)))
+ph = list(out)[26:31]
+if sum(ph):
+    print("exact value requests served, by phase: " + ", ".join("%s %d (%.2f/segment)" % (n, v, v / max(med.counters()[1], 1))
+                                                               for n, v in zip(("X_F0", "X_CUR", "X_PREV", "X_REFINE", "X_FINAL"), ph)))
 print("lane evals", med.counters(), "guide steps", med.guide_steps())
 print("active lanes per exact wave-eval: %.1f" % (med.counters()[0] / e))
