@@ -358,6 +358,29 @@ void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint
 int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum,
                         uint32_t *hit_count, void *stream);
 
+/* Specular micro-surface + light of finite solid angle for gpis_render_scene_s_nee. 32 bytes. */
+typedef struct gpis_surface_s {
+    float eta, k;             /* ConductorBsdf "eta", "k" (one channel; Fresnel.hpp:102-123) */
+    float albedo;
+    float cap_cos;            /* the light: an infinite spherical cap about scene.light_dir, cos of its half-angle
+                                 (InfiniteSphereCap "cap_angle") */
+    float cap_radiance;
+    float _pad[3];
+} gpis_surface_s;
+
+/* Scene S with the reference's specular NEE coupling: per sample the primary
+ * sampleDistance, then TraceBase::volumeEstimateDirect = volumeLightSample + volumePhaseSample
+ * (TraceBase.cpp:346-420) for a BRDFPhaseFunction over a ConductorBsdf (BRDFPhaseFunction.cpp:27-96,
+ * ConductorBsdf.cpp:59-139) and one InfiniteSphereCap light:
+ *   light sample (schemes NEE, MIS): f = albedo * F(wi.z) * neePDF(half-vector normal); the shadow segment
+ *     runs on a state copy whose lastAniso = neeGrad(half-vector normal); weight power-heuristic unless NEE;
+ *   phase sample (schemes UNI, MIS): mirror direction about the sampled normal, pdf = neePDF(normal), counts
+ *     when it falls inside the cap.
+ * The scheme is the one sampleDistance reports per sample (gpis_seg_out.scheme).  The cap direction is drawn
+ * with a rejection-sampled azimuth (sqrt only) instead of SampleWarp::uniformSphericalCap's sin/cos. */
+int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, const gpis_surface_s *surf,
+                            float *radiance_sum, void *stream);
+
 /* Multi-bounce wavefront driver on scene S: per sample, up to `max_path_bounces`
  * medium interactions following PathTracer::traceSample / TraceBase::handleVolume
  * (PathTracer.cpp:62-75, TraceBase.cpp:539-563):

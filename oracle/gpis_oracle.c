@@ -2075,6 +2075,171 @@ int oracle_render_scene_s_paths(oracle_medium *m, const gpis_scene_s *s, int max
     return GPIS_OK;
 }
 
+/* --------------------------------------------------------------------------------------
+ * Scene S with the specular NEE coupling (TraceBase.cpp:346-420, BRDFPhaseFunction.cpp:27-96,
+ * ConductorBsdf.cpp:59-139, Fresnel.hpp:102-123, InfiniteSphereCap).  Per sample one PCG stream:
+ * jx, jy, u_march, then [cap z, azimuth rejection draws, u_shadow] for the light sample and
+ * [u_shadow] for the phase sample when its direction falls inside the cap.
+ * ------------------------------------------------------------------------------------ */
+static float conductor_reflectance(float eta, float k, float cosThetaI)   /* Fresnel.hpp:102-123 */
+{
+    if (eta == 0 && k == 0)
+        return 1;
+    float cosThetaISq = cosThetaI * cosThetaI;
+    float sinThetaISq = 1.0f - cosThetaISq > 0.0f ? 1.0f - cosThetaISq : 0.0f;
+    float sinThetaIQu = sinThetaISq * sinThetaISq;
+    float innerTerm = eta * eta - k * k - sinThetaISq;
+    float q = innerTerm * innerTerm + 4.0f * eta * eta * k * k;
+    float aSqPlusBSq = sqrtf(q > 0.0f ? q : 0.0f);
+    float h = (aSqPlusBSq + innerTerm) * 0.5f;
+    float a = sqrtf(h > 0.0f ? h : 0.0f);
+    float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f * a * cosThetaI)) /
+               ((aSqPlusBSq + cosThetaISq) + (2.0f * a * cosThetaI));
+    float Rp = ((cosThetaISq * aSqPlusBSq + sinThetaIQu) - (2.0f * a * cosThetaI * sinThetaISq)) /
+               ((cosThetaISq * aSqPlusBSq + sinThetaIQu) + (2.0f * a * cosThetaI * sinThetaISq));
+    return 0.5f * (Rs + Rs * Rp);
+}
+static float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }   /* SampleWarp.hpp */
+
+static float scene_nee_sample(oracle_medium *m, oracle_counters *cnt, const gpis_scene_s *s, const gpis_surface_s *sf,
+                              uint32_t px, uint32_t py, uint32_t spp)
+{
+    gpis_ray_in ray;
+    float u_unused;
+    if (!oracle_scene_s_primary(s, px, py, spp, &ray, &u_unused))
+        return 0.f;
+    pcg32 g;
+    pcg_set_state(&g, (uint64_t)(uint32_t)(xxhash32_4(px, py, spp, s->scene_seed) + 1u));
+    (void)pcg_next_1d(&g); (void)pcg_next_1d(&g); (void)pcg_next_1d(&g);   /* jx, jy, u_march */
+    gpis_seg_out o;
+    gpis_cond_coeff coeff;
+    sample_distance_one(m, cnt, &ray, &o, &coeff);
+    if (!o.ok || o.exited)
+        return 0.f;
+    const int scheme = o.scheme;
+    v3f capDir = v3_normalized(v3(s->light_dir[0], s->light_dir[1], s->light_dir[2]));
+    const float pdf_l = (0.5f * INV_PI_F) / (1.0f - sf->cap_cos);   /* uniformSphericalCapPdf */
+    /* BRDFPhaseFunction::setEventIsectInfo */
+    double ax = o.aniso[0], ay = o.aniso[1], az = o.aniso[2];
+    double len = sqrt(ax * ax + ay * ay + az * az);
+    v3f n = v3((float)(ax / len), (float)(ay / len), (float)(az / len));
+    frame fr = frame_from_normal(n);
+    v3f dir = v3(ray.dir[0], ray.dir[1], ray.dir[2]);
+    v3f wi = v3_normalized(frame_to_local(&fr, v3(-dir.x, -dir.y, -dir.z)));
+    v3f p = v3(o.p[0], o.p[1], o.p[2]);
+    ray_info rinfo = {px, py, spp, ray.segment, s->scene_seed, ray.info_t + o.sample_t};
+    const float F = sf->albedo * conductor_reflectance(sf->eta, sf->k, wi.z);
+    /* the state volumeEstimateDirect works on: handleVolume's copy with the segment word + 1 */
+    gpis_ray_in sh0;
+    memset(&sh0, 0, sizeof sh0);
+    sh0.pos[0] = p.x; sh0.pos[1] = p.y; sh0.pos[2] = p.z;
+    sh0.near_t = 0.f;
+    sh0.pixel[0] = px; sh0.pixel[1] = py; sh0.spp = spp;
+    sh0.segment = ray.segment + 1;
+    sh0.scene_seed = s->scene_seed;
+    sh0.info_t = ray.info_t + o.sample_t;
+    sh0.first_scatter = 0;
+    sh0.bounce = ray.bounce + 1;
+    sh0.last_val = o.last_val;
+    sh0.last_gp_id = o.gp_id;
+    sh0.last_aniso[0] = o.aniso[0]; sh0.last_aniso[1] = o.aniso[1]; sh0.last_aniso[2] = o.aniso[2];
+    float L = 0.f;
+    realization r;
+    if (scheme != GPIS_UNI) {   /* volumeLightSample */
+        float z = pcg_next_1d(&g) * (1.0f - sf->cap_cos) + sf->cap_cos;
+        float dx, dy, d2;
+        do {
+            dx = 2.f * pcg_next_1d(&g) - 1.f;
+            dy = 2.f * pcg_next_1d(&g) - 1.f;
+            d2 = dx * dx + dy * dy;
+        } while (!(d2 < 1.f) || !(d2 > 1e-12f));
+        float rr = 1.0f - z * z;
+        float rad = sqrtf(rr > 0.f ? rr : 0.f) / sqrtf(d2);
+        frame cf = frame_from_normal(capDir);
+        v3f d = frame_to_global(&cf, v3(dx * rad, dy * rad, z));
+        v3f wo = v3_normalized(frame_to_local(&fr, d));
+        v3f nl = v3_scale(v3_add(wi, wo), 0.5f);
+        v3f nw = v3_normalized(frame_to_global(&fr, nl));
+        realization_of(m, cnt, &coeff, &r);
+        float pdf = nee_pdf(&r, dir, nw, p, o.sample_t, rinfo);
+        float f = F * pdf;
+        if (f != 0.0f) {
+            realization_of(m, cnt, &coeff, &r);
+            v3f gr = nee_grad(&r, dir, nw, p, rinfo);
+            float t0, t1;
+            if (sphere_chord(p, d, s->bound_radius, &t0, &t1)) {
+                gpis_ray_in sh = sh0;
+                sh.dir[0] = d.x; sh.dir[1] = d.y; sh.dir[2] = d.z;
+                sh.far_t = t1;
+                sh.u_jitter = pcg_next_1d(&g);
+                sh.last_aniso[0] = gr.x; sh.last_aniso[1] = gr.y; sh.last_aniso[2] = gr.z;
+                medium_state st;
+                state_from_ray(&sh, &st);
+                cnt->n_seg++;
+                int vis = transmittance_one(m, cnt, &sh, &st);
+                float e = (vis ? 1.f : 0.f) * sf->cap_radiance;
+                if (e != 0.0f) {
+                    float lightF = f * e / pdf_l;
+                    if (scheme != GPIS_NEE)
+                        lightF *= power_heuristic(pdf_l, pdf);
+                    L += lightF;
+                }
+            }
+        }
+    }
+    if (scheme != GPIS_NEE) {   /* volumePhaseSample: ConductorBsdf::sample mirrors about the sampled normal */
+        v3f wo = v3(-wi.x, -wi.y, wi.z);
+        float pdf_p = 1.0f;
+        if (scheme != GPIS_UNI) {
+            realization_of(m, cnt, &coeff, &r);
+            pdf_p = nee_pdf(&r, dir, n, p, o.sample_t, rinfo);
+        }
+        v3f w = v3_normalized(frame_to_global(&fr, wo));
+        float t0, t1;
+        if (!(v3_dot(w, capDir) < sf->cap_cos) && sphere_chord(p, w, s->bound_radius, &t0, &t1)) {
+            gpis_ray_in sh = sh0;
+            sh.dir[0] = w.x; sh.dir[1] = w.y; sh.dir[2] = w.z;
+            sh.far_t = t1;
+            sh.u_jitter = pcg_next_1d(&g);
+            medium_state st;
+            state_from_ray(&sh, &st);
+            cnt->n_seg++;
+            int vis = transmittance_one(m, cnt, &sh, &st);
+            float e = (vis ? 1.f : 0.f) * sf->cap_radiance;
+            if (e != 0.0f) {
+                float phaseF = e * F;
+                if (scheme != GPIS_UNI)
+                    phaseF *= power_heuristic(pdf_p, pdf_l);
+                L += phaseF;
+            }
+        }
+    }
+    return L;
+}
+
+typedef struct { const gpis_scene_s *s; const gpis_surface_s *sf; float *rad; } nee_scene_ctx;
+static void nee_scene_range(oracle_medium *m, oracle_counters *cnt, size_t i0, size_t i1, void *c)
+{
+    nee_scene_ctx *x = (nee_scene_ctx *)c;
+    const gpis_scene_s *s = x->s;
+    for (size_t idx = i0; idx < i1; ++idx) {
+        uint32_t py = s->y_begin + (uint32_t)(idx / s->width), px = (uint32_t)(idx % s->width);
+        float acc = 0.f;
+        for (uint32_t k = 0; k < s->spp_count; ++k)
+            acc += scene_nee_sample(m, cnt, s, x->sf, px, py, s->spp_begin + k);
+        x->rad[(size_t)py * s->width + px] += acc;
+    }
+}
+int oracle_render_scene_s_nee(oracle_medium *m, const gpis_scene_s *s, const gpis_surface_s *surf, float *radiance_sum)
+{
+    if (!m || !s || !surf || !radiance_sum) return fail("null argument");
+    if (s->y_begin + s->y_count > s->height) return fail("row range outside the image");
+    if (!(surf->cap_cos < 1.0f) || !(surf->cap_cos > -1.0f)) return fail("cap_cos must lie in (-1, 1)");
+    nee_scene_ctx c = {s, surf, radiance_sum};
+    parallel_for(m, (size_t)s->y_count * s->width, nee_scene_range, &c);
+    return GPIS_OK;
+}
+
 /* ======================================================================================
  * Pinning surface
  * ==================================================================================== */

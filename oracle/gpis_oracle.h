@@ -55,6 +55,7 @@ void oracle_reset_counters(oracle_medium *m);
 
 void oracle_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp);
 int oracle_render_scene_s(oracle_medium *m, const gpis_scene_s *s, float *radiance_sum, uint32_t *hit_count);
+int oracle_render_scene_s_nee(oracle_medium *m, const gpis_scene_s *s, const gpis_surface_s *surf, float *radiance_sum);
 int oracle_render_scene_s_paths(oracle_medium *m, const gpis_scene_s *s, int max_path_bounces, float albedo, float *radiance_sum);
 /* Scene-S building blocks (so the GPU driver's ray generation can be checked on its own):
  * primary ray + draws of sample (x, y, spp); returns 0 if the ray misses the bounding sphere. */

@@ -15,8 +15,8 @@ sys.path.insert(0, os.path.dirname(_HERE))
 import _gpis_pkg  # noqa: E402
 
 _T = _gpis_pkg.load_package()
-PARAMS, RAY_IN, SEG_OUT, COND_COEFF, QUERY, NEE_QUERY, DERIVED, SCENE_S = (
-    _T.PARAMS, _T.RAY_IN, _T.SEG_OUT, _T.COND_COEFF, _T.QUERY, _T.NEE_QUERY, _T.DERIVED, _T.SCENE_S)
+PARAMS, RAY_IN, SEG_OUT, COND_COEFF, QUERY, NEE_QUERY, DERIVED, SCENE_S, SURFACE_S = (
+    _T.PARAMS, _T.RAY_IN, _T.SEG_OUT, _T.COND_COEFF, _T.QUERY, _T.NEE_QUERY, _T.DERIVED, _T.SCENE_S, _T.SURFACE_S)
 
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libgpis_ref.so")
@@ -60,6 +60,7 @@ class Oracle:
         L.oracle_render_scene_s.argtypes = [_vp, _vp, _vp, _vp]
         L.oracle_scene_s_primary.argtypes = [_vp, _u32, _u32, _u32, _vp, _vp]
         L.oracle_render_scene_s_paths.argtypes = [_vp, _vp, _i32, _f32, _vp]
+        L.oracle_render_scene_s_nee.argtypes = [_vp, _vp, _vp, _vp]
         self.params = np.array(params, dtype=PARAMS)
         h = _vp()
         st = L.oracle_create(_p(self.params), ctypes.byref(h))
@@ -144,6 +145,13 @@ class Oracle:
         hits = np.zeros_like(rad, dtype=np.uint32) if want_hits else None
         assert self.lib.oracle_render_scene_s(self.h, _p(scene), _p(rad), _p(hits)) == 0
         return (rad, hits) if want_hits else rad
+
+    def render_scene_s_nee(self, scene, surface):
+        scene = np.array(scene, dtype=SCENE_S)
+        surface = np.array(surface, dtype=SURFACE_S)
+        rad = np.zeros((int(scene["height"]), int(scene["width"])), dtype=np.float32)
+        assert self.lib.oracle_render_scene_s_nee(self.h, _p(scene), _p(surface), _p(rad)) == 0
+        return rad
 
     def render_scene_s_paths(self, scene, max_bounces, albedo):
         scene = np.array(scene, dtype=SCENE_S)

@@ -89,10 +89,24 @@ SCENE_S = np.dtype([
     ("y_begin", "<u4"), ("y_count", "<u4"),
 ], align=True)
 
+SURFACE_S = np.dtype([
+    ("eta", "<f4"), ("k", "<f4"), ("albedo", "<f4"), ("cap_cos", "<f4"), ("cap_radiance", "<f4"), ("_pad", "<f4", 3),
+], align=True)
+
+
+def default_surface_s():
+    """Copper-like single-channel conductor and a 12-degree cap light."""
+    s = np.zeros((), dtype=SURFACE_S)
+    s["eta"], s["k"], s["albedo"] = 0.2, 3.9, 1.0
+    s["cap_cos"], s["cap_radiance"] = 0.9781476, 20.0
+    return s
+
+
 _EXPECTED_SIZES = {
     "gpis_params": PARAMS.itemsize, "gpis_mean": MEAN.itemsize, "gpis_ray_in": RAY_IN.itemsize,
     "gpis_seg_out": SEG_OUT.itemsize, "gpis_cond_coeff": COND_COEFF.itemsize, "gpis_query": QUERY.itemsize,
     "gpis_nee_query": NEE_QUERY.itemsize, "gpis_derived": DERIVED.itemsize, "gpis_scene_s": SCENE_S.itemsize,
+    "gpis_surface_s": SURFACE_S.itemsize,
 }
 assert RAY_IN.itemsize == 128 and SEG_OUT.itemsize == 96 and COND_COEFF.itemsize == 32
 assert QUERY.itemsize == 96 and NEE_QUERY.itemsize == 96
@@ -197,7 +211,7 @@ class GpisLib:
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
         "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
-        "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths",
+        "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
     ]
 
     def __init__(self, path=None):
@@ -253,6 +267,7 @@ class GpisLib:
         L.gpis_default_scene_s.restype = None
         L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
         L.gpis_render_scene_s_paths.argtypes = [vp, vp, i32, ctypes.c_float, vp, vp]
+        L.gpis_render_scene_s_nee.argtypes = [vp, vp, vp, vp, vp]
         if hasattr(L, "gpis_abi_sizes"):
             L.gpis_abi_sizes.restype = ctypes.c_char_p
             got = dict(kv.split("=") for kv in L.gpis_abi_sizes().decode().split(","))

@@ -375,11 +375,12 @@ __global__ void __launch_bounds__(kBlock) k_conditioning(const DevModel *__restr
     flush_counters(cnt, r.n_eval, 0);
 }
 __global__ void __launch_bounds__(kBlock) k_nee(const DevModel *__restrict__ Mp, size_t n, const gpis_nee_query *__restrict__ q,
-                                                float *__restrict__ pdf, float *__restrict__ grad3, Counters *cnt)
+                                                float *__restrict__ pdf, float *__restrict__ grad3, Counters *cnt,
+                                                const uint8_t *__restrict__ mask = nullptr)
 {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     Realization r{};
-    if (i < n) {
+    if (i < n && (!mask || mask[i])) {
         gpis_nee_query qq = q[i];
         r.c = qq.coeff;
         V3 rd = v3(qq.ray_dir[0], qq.ray_dir[1], qq.ray_dir[2]), nn = v3(qq.normal[0], qq.normal[1], qq.normal[2]), p = v3(qq.p[0], qq.p[1], qq.p[2]);
@@ -675,6 +676,201 @@ __global__ void __launch_bounds__(256) k_paths_accumulate(uint32_t spp, size_t f
     radiance_sum[first_pixel + j] += acc;
 }
 
+// --------------------------------------------------------------------------------------
+// scene S with the specular NEE coupling (gpis_render_scene_s_nee): TraceBase.cpp:346-420,
+// BRDFPhaseFunction.cpp:27-96, ConductorBsdf.cpp:59-139, Fresnel.hpp:102-123.
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ float conductor_reflectance(float eta, float k, float cosThetaI)
+{
+    if (eta == 0 && k == 0)
+        return 1;
+    float cosThetaISq = cosThetaI * cosThetaI;
+    float sinThetaISq = 1.0f - cosThetaISq > 0.0f ? 1.0f - cosThetaISq : 0.0f;
+    float sinThetaIQu = sinThetaISq * sinThetaISq;
+    float innerTerm = eta * eta - k * k - sinThetaISq;
+    float q = innerTerm * innerTerm + 4.0f * eta * eta * k * k;
+    float aSqPlusBSq = sqrtf(q > 0.0f ? q : 0.0f);
+    float h = (aSqPlusBSq + innerTerm) * 0.5f;
+    float a = sqrtf(h > 0.0f ? h : 0.0f);
+    float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f * a * cosThetaI)) /
+               ((aSqPlusBSq + cosThetaISq) + (2.0f * a * cosThetaI));
+    float Rp = ((cosThetaISq * aSqPlusBSq + sinThetaIQu) - (2.0f * a * cosThetaI * sinThetaISq)) /
+               ((cosThetaISq * aSqPlusBSq + sinThetaIQu) + (2.0f * a * cosThetaI * sinThetaISq));
+    return 0.5f * (Rs + Rs * Rp);
+}
+__device__ __forceinline__ float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }
+
+struct NeeAux {            // per sample, between the set-up and the shading kernel
+    float d[3];            // sampled light direction
+    float w[3];            // mirror direction of the phase sample
+    float F;               // albedo * conductorReflectance(wi.z)
+    float v1, v2;          // the next two draws of the sample's stream (march jitters of the shadow segments)
+    int32_t scheme;
+};
+struct NeeArrays {
+    gpis_cond_coeff *coeff;
+    gpis_nee_query *q_half, *q_normal;
+    NeeAux *aux;
+    gpis_ray_in *shadow_light, *shadow_phase;
+    float *pdf_half, *grad_half, *pdf_normal;
+    float *contrib_light, *contrib_phase;
+    uint8_t *want_light, *want_phase, *want_pdf_normal, *go_light, *go_phase, *vis_light, *vis_phase;
+};
+
+__global__ void __launch_bounds__(256) k_nee_setup(SceneConst sc, gpis_surface_s sf, size_t n_samples, PathArrays a, NeeArrays b)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    uint8_t wl = 0, wp = 0, wn = 0;
+    const gpis_seg_out o = a.seg[i];
+    if (a.alive[i] && o.ok && !o.exited) {
+        const gpis_ray_in ray = a.rays[i];
+        Pcg32 g;
+        g.state = a.rng[i];
+        NeeAux x;
+        x.scheme = o.scheme;
+        const V3 capDir = v3(sc.light[0], sc.light[1], sc.light[2]);
+        const double ax = o.aniso[0], ay = o.aniso[1], az = o.aniso[2];
+        const double len = sqrt(ax * ax + ay * ay + az * az);
+        const V3 n = v3((float)(ax / len), (float)(ay / len), (float)(az / len));
+        const Frame fr = frame_from_normal(n);
+        const V3 dir = v3(ray.dir[0], ray.dir[1], ray.dir[2]);
+        const V3 wi = normalized(to_local(fr, v3(-dir.x, -dir.y, -dir.z)));
+        x.F = sf.albedo * conductor_reflectance(sf.eta, sf.k, wi.z);
+        gpis_nee_query q;
+        memset(&q, 0, sizeof q);
+        q.ray_dir[0] = dir.x; q.ray_dir[1] = dir.y; q.ray_dir[2] = dir.z;
+        q.p[0] = o.p[0]; q.p[1] = o.p[1]; q.p[2] = o.p[2];
+        q.t_segment = o.sample_t;
+        q.info_t = ray.info_t + o.sample_t;
+        q.pixel[0] = ray.pixel[0]; q.pixel[1] = ray.pixel[1]; q.spp = ray.spp; q.segment = ray.segment;
+        q.scene_seed = ray.scene_seed;
+        q.coeff = b.coeff[i];
+        x.d[0] = x.d[1] = x.d[2] = 0.f;
+        if (x.scheme != GPIS_UNI) {     // volumeLightSample: a direction inside the cap
+            const float z = normalized_uint(g.next_i()) * (1.0f - sf.cap_cos) + sf.cap_cos;
+            float dx, dy, d2;
+            do {
+                dx = 2.f * normalized_uint(g.next_i()) - 1.f;
+                dy = 2.f * normalized_uint(g.next_i()) - 1.f;
+                d2 = dx * dx + dy * dy;
+            } while (!(d2 < 1.f) || !(d2 > 1e-12f));
+            const float rr = 1.0f - z * z;
+            const float rad = sqrtf(rr > 0.f ? rr : 0.f) / sqrtf(d2);
+            const Frame cf = frame_from_normal(capDir);
+            const V3 d = to_global(cf, v3(dx * rad, dy * rad, z));
+            const V3 wo = normalized(to_local(fr, d));
+            const V3 nl = (wi + wo) * 0.5f;
+            const V3 nw = normalized(to_global(fr, nl));
+            x.d[0] = d.x; x.d[1] = d.y; x.d[2] = d.z;
+            gpis_nee_query qh = q;
+            qh.normal[0] = nw.x; qh.normal[1] = nw.y; qh.normal[2] = nw.z;
+            b.q_half[i] = qh;
+            wl = 1;
+        }
+        x.w[0] = x.w[1] = x.w[2] = 0.f;
+        if (x.scheme != GPIS_NEE) {     // volumePhaseSample: mirror about the sampled normal
+            const V3 w = normalized(to_global(fr, v3(-wi.x, -wi.y, wi.z)));
+            x.w[0] = w.x; x.w[1] = w.y; x.w[2] = w.z;
+            float t0, t1;
+            if (!(dot(w, capDir) < sf.cap_cos) && sphere_chord(v3(o.p[0], o.p[1], o.p[2]), w, sc.s.bound_radius, t0, t1)) {
+                wp = 1;
+                if (x.scheme != GPIS_UNI) {
+                    gpis_nee_query qn = q;
+                    qn.normal[0] = n.x; qn.normal[1] = n.y; qn.normal[2] = n.z;
+                    b.q_normal[i] = qn;
+                    wn = 1;
+                }
+            }
+        }
+        x.v1 = normalized_uint(g.next_i());
+        x.v2 = normalized_uint(g.next_i());
+        b.aux[i] = x;
+    }
+    b.want_light[i] = wl;
+    b.want_phase[i] = wp;
+    b.want_pdf_normal[i] = wn;
+}
+
+__global__ void __launch_bounds__(256) k_nee_shade(SceneConst sc, gpis_surface_s sf, size_t n_samples, PathArrays a, NeeArrays b)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    uint8_t gl = 0, gp = 0;
+    if (b.want_light[i] || b.want_phase[i]) {
+        const gpis_seg_out o = a.seg[i];
+        const gpis_ray_in ray = a.rays[i];
+        const NeeAux x = b.aux[i];
+        const float pdf_l = (0.5f * (1.0f / 3.1415926536f)) / (1.0f - sf.cap_cos);
+        const V3 p = v3(o.p[0], o.p[1], o.p[2]);
+        gpis_ray_in sh0;
+        memset(&sh0, 0, sizeof sh0);
+        sh0.pos[0] = p.x; sh0.pos[1] = p.y; sh0.pos[2] = p.z;
+        sh0.near_t = 0.f;
+        sh0.pixel[0] = ray.pixel[0]; sh0.pixel[1] = ray.pixel[1]; sh0.spp = ray.spp;
+        sh0.segment = ray.segment + 1;
+        sh0.scene_seed = ray.scene_seed;
+        sh0.info_t = ray.info_t + o.sample_t;
+        sh0.first_scatter = 0;
+        sh0.bounce = ray.bounce + 1;
+        sh0.last_val = o.last_val;
+        sh0.last_gp_id = o.gp_id;
+        sh0.last_aniso[0] = o.aniso[0]; sh0.last_aniso[1] = o.aniso[1]; sh0.last_aniso[2] = o.aniso[2];
+        bool light_drew = false;
+        if (b.want_light[i]) {
+            const float pdf = b.pdf_half[i];
+            const float f = x.F * pdf;
+            float t0, t1;
+            const V3 d = v3(x.d[0], x.d[1], x.d[2]);
+            if (f != 0.0f && sphere_chord(p, d, sc.s.bound_radius, t0, t1)) {
+                gpis_ray_in sh = sh0;
+                sh.dir[0] = d.x; sh.dir[1] = d.y; sh.dir[2] = d.z;
+                sh.far_t = t1;
+                sh.u_jitter = x.v1;
+                sh.last_aniso[0] = (double)b.grad_half[3 * i]; sh.last_aniso[1] = (double)b.grad_half[3 * i + 1]; sh.last_aniso[2] = (double)b.grad_half[3 * i + 2];
+                b.shadow_light[i] = sh;
+                const float e = 1.f * sf.cap_radiance;
+                float lightF = f * e / pdf_l;
+                if (x.scheme != GPIS_NEE)
+                    lightF *= power_heuristic(pdf_l, pdf);
+                b.contrib_light[i] = lightF;
+                light_drew = true;
+                gl = 1;
+            }
+        }
+        if (b.want_phase[i]) {
+            float t0, t1;
+            const V3 w = v3(x.w[0], x.w[1], x.w[2]);
+            (void)sphere_chord(p, w, sc.s.bound_radius, t0, t1);   // known to succeed (k_nee_setup)
+            gpis_ray_in sh = sh0;
+            sh.dir[0] = w.x; sh.dir[1] = w.y; sh.dir[2] = w.z;
+            sh.far_t = t1;
+            sh.u_jitter = light_drew ? x.v2 : x.v1;
+            b.shadow_phase[i] = sh;
+            const float e = 1.f * sf.cap_radiance;
+            float phaseF = e * x.F;
+            if (x.scheme != GPIS_UNI)
+                phaseF *= power_heuristic(b.pdf_normal[i], pdf_l);
+            b.contrib_phase[i] = phaseF;
+            gp = 1;
+        }
+    }
+    b.go_light[i] = gl;
+    b.go_phase[i] = gp;
+}
+
+__global__ void __launch_bounds__(256) k_nee_gather(float cap_radiance, size_t n_samples, PathArrays a, NeeArrays b)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    float L = 0.f;
+    if (cap_radiance != 0.0f) {     // e == 0 ends both estimators (TraceBase.cpp:374, 410)
+        if (b.go_light[i] && b.vis_light[i]) L += b.contrib_light[i];
+        if (b.go_phase[i] && b.vis_phase[i]) L += b.contrib_phase[i];
+    }
+    a.emission[i] = L;
+}
+
 // ======================================================================================
 // C ABI
 // ======================================================================================
@@ -685,9 +881,9 @@ extern "C" const char *gpis_abi_sizes(void)
     static char buf[512];
     snprintf(buf, sizeof buf,
              "gpis_params=%zu,gpis_mean=%zu,gpis_ray_in=%zu,gpis_seg_out=%zu,gpis_cond_coeff=%zu,gpis_query=%zu,"
-             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu",
+             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu,gpis_surface_s=%zu",
              sizeof(gpis_params), sizeof(gpis_mean), sizeof(gpis_ray_in), sizeof(gpis_seg_out), sizeof(gpis_cond_coeff),
-             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s));
+             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s), sizeof(gpis_surface_s));
     return buf;
 }
 
@@ -1308,6 +1504,68 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
             k_paths_nee_add<<<grid_of(ns, 256), 256, 0, st>>>(ns, a);
             if ((rc = launch_check("k_paths_nee_add"))) return rc;
         }
+        k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(s->spp_count, first_pixel0 + p0, np, a.emission, radiance_sum);
+        if ((rc = launch_check("k_paths_accumulate"))) return rc;
+    }
+    return GPIS_OK;
+}
+
+extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, const gpis_surface_s *surf, float *radiance_sum, void *stream)
+{
+    CHECK_ARGS(m && s && surf && radiance_sum);
+    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
+    CHECK_ARGS(surf->cap_cos < 1.0f && surf->cap_cos > -1.0f);
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    SceneConst sc = make_scene_const(s);
+    const size_t total_pixels = (size_t)s->y_count * s->width;
+    const size_t first_pixel0 = (size_t)s->y_begin * s->width;
+    size_t chunk_pixels = ((size_t)1 << 22) / s->spp_count;
+    if (chunk_pixels < 1) chunk_pixels = 1;
+    if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
+    const size_t ns_max = chunk_pixels * s->spp_count;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    PathArrays a;
+    NeeArrays b;
+    size_t o_rays = carve(ns_max * sizeof(gpis_ray_in)), o_seg = carve(ns_max * sizeof(gpis_seg_out));
+    size_t o_rng = carve(ns_max * 8), o_thr = carve(ns_max * 4), o_em = carve(ns_max * 4), o_alive = carve(ns_max);
+    size_t o_coeff = carve(ns_max * sizeof(gpis_cond_coeff)), o_qh = carve(ns_max * sizeof(gpis_nee_query)), o_qn = carve(ns_max * sizeof(gpis_nee_query));
+    size_t o_aux = carve(ns_max * sizeof(NeeAux)), o_shl = carve(ns_max * sizeof(gpis_ray_in)), o_shp = carve(ns_max * sizeof(gpis_ray_in));
+    size_t o_ph = carve(ns_max * 4), o_gh = carve(ns_max * 12), o_pn = carve(ns_max * 4), o_cl = carve(ns_max * 4), o_cp = carve(ns_max * 4);
+    size_t o_f[7];
+    for (int k = 0; k < 7; ++k) o_f[k] = carve(ns_max);
+    int rc = ensure_stage(m, 3, off);
+    if (rc) return rc;
+    char *ws = (char *)m->stage[3];
+    a.rays = (gpis_ray_in *)(ws + o_rays); a.seg = (gpis_seg_out *)(ws + o_seg); a.shadow = nullptr;
+    a.rng = (uint64_t *)(ws + o_rng); a.throughput = (float *)(ws + o_thr); a.emission = (float *)(ws + o_em); a.contrib = nullptr;
+    a.alive = (uint8_t *)(ws + o_alive); a.nee = nullptr; a.vis = nullptr;
+    b.coeff = (gpis_cond_coeff *)(ws + o_coeff); b.q_half = (gpis_nee_query *)(ws + o_qh); b.q_normal = (gpis_nee_query *)(ws + o_qn);
+    b.aux = (NeeAux *)(ws + o_aux); b.shadow_light = (gpis_ray_in *)(ws + o_shl); b.shadow_phase = (gpis_ray_in *)(ws + o_shp);
+    b.pdf_half = (float *)(ws + o_ph); b.grad_half = (float *)(ws + o_gh); b.pdf_normal = (float *)(ws + o_pn);
+    b.contrib_light = (float *)(ws + o_cl); b.contrib_phase = (float *)(ws + o_cp);
+    b.want_light = (uint8_t *)(ws + o_f[0]); b.want_phase = (uint8_t *)(ws + o_f[1]); b.want_pdf_normal = (uint8_t *)(ws + o_f[2]);
+    b.go_light = (uint8_t *)(ws + o_f[3]); b.go_phase = (uint8_t *)(ws + o_f[4]); b.vis_light = (uint8_t *)(ws + o_f[5]); b.vis_phase = (uint8_t *)(ws + o_f[6]);
+    for (size_t p0 = 0; p0 < total_pixels; p0 += chunk_pixels) {
+        size_t np = total_pixels - p0 < chunk_pixels ? total_pixels - p0 : chunk_pixels;
+        size_t ns = np * s->spp_count;
+        k_paths_begin<<<grid_of(ns, 256), 256, 0, st>>>(sc, first_pixel0 + p0, ns, a);
+        if ((rc = launch_check("k_paths_begin"))) return rc;
+        if ((rc = sample_distance_impl(m, ns, a.rays, a.seg, b.coeff, a.alive, st))) return rc;
+        k_nee_setup<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);
+        if ((rc = launch_check("k_nee_setup"))) return rc;
+        k_nee<<<grid_of(ns, kBlock), kBlock, 0, st>>>(m->d_model, ns, b.q_half, b.pdf_half, b.grad_half, m->d_counters, b.want_light);
+        if ((rc = launch_check("k_nee"))) return rc;
+        k_nee<<<grid_of(ns, kBlock), kBlock, 0, st>>>(m->d_model, ns, b.q_normal, b.pdf_normal, nullptr, m->d_counters, b.want_pdf_normal);
+        if ((rc = launch_check("k_nee"))) return rc;
+        k_nee_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);
+        if ((rc = launch_check("k_nee_shade"))) return rc;
+        if ((rc = transmittance_impl(m, ns, b.shadow_light, b.vis_light, b.go_light, st))) return rc;
+        if ((rc = transmittance_impl(m, ns, b.shadow_phase, b.vis_phase, b.go_phase, st))) return rc;
+        k_nee_gather<<<grid_of(ns, 256), 256, 0, st>>>(surf->cap_radiance, ns, a, b);
+        if ((rc = launch_check("k_nee_gather"))) return rc;
         k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(s->spp_count, first_pixel0 + p0, np, a.emission, radiance_sum);
         if ((rc = launch_check("k_paths_accumulate"))) return rc;
     }

@@ -126,6 +126,10 @@ def oracle_vectors():
     # the same scene through the multi-bounce driver: 4 path bounces, albedo 0.8
     paths = orc.render_scene_s_paths(ob.default_scene_s(64, 64, 4), 4, 0.8)
     np.savez_compressed(os.path.join(HERE, "oracle_C0_image64.npz"), radiance_sum=rad, hits=hits, paths_radiance_sum=paths)
+    # scene S with the specular NEE coupling on the C2 medium (1D sampling, MIS scheme): 48x48, 2 spp
+    orc = ob.Oracle(pkg.params_for_config("C2"), threads=8)
+    nee = orc.render_scene_s_nee(ob.default_scene_s(48, 48, 2), pkg.default_surface_s())
+    np.savez_compressed(os.path.join(HERE, "image_C2_nee48.npz"), radiance_sum=nee, surface=pkg.default_surface_s())
 
 
 def reference_kat():

@@ -86,3 +86,28 @@ def test_oracle_image_fixture(pkg, ob):
     assert np.array_equal(rad, g["radiance_sum"]) and np.array_equal(hits, g["hits"])
     paths = orc.render_scene_s_paths(ob.default_scene_s(64, 64, 4), 4, 0.8)
     assert np.array_equal(paths, g["paths_radiance_sum"]) and paths.sum() > 0
+
+
+def test_oracle_nee_image_fixture(pkg, ob):
+    g = np.load(os.path.join(GOLD, "image_C2_nee48.npz"))
+    orc = ob.Oracle(pkg.params_for_config("C2"), threads=8)
+    rad = orc.render_scene_s_nee(ob.default_scene_s(48, 48, 2), g["surface"])
+    assert np.array_equal(rad, g["radiance_sum"]) and rad.sum() > 0
+
+
+def test_nee_estimators_agree(pkg, ob):
+    """volumeLightSample weighted by neePDF and volumePhaseSample (mirror about the sampled normal) estimate
+    the same integral (TraceBase.cpp:346-420): the UNI, NEE and MIS schemes must agree in the mean.  This is
+    the statistical check that neePDF is the density of the mirrored direction."""
+    sums = {}
+    surf = pkg.default_surface_s()
+    surf["cap_cos"] = 0.9      # a wide cap, so that the phase-sampling-only estimator is not too noisy
+    for name, scheme in (("uni", 0), ("nee", 1), ("mis", 2)):
+        p = pkg.params_for_config("C2")
+        p["scheme_1d"] = scheme
+        orc = ob.Oracle(p, threads=8)
+        sums[name] = float(orc.render_scene_s_nee(ob.default_scene_s(96, 96, 4), surf).sum())
+    print(sums)
+    assert sums["nee"] > 0
+    assert abs(sums["mis"] - sums["nee"]) < 0.03 * sums["nee"]
+    assert abs(sums["uni"] - sums["nee"]) < 0.10 * sums["nee"]

@@ -487,6 +487,40 @@ def test_render_scene_s_paths(env, path):
     assert med.L.lib.gpis_render_scene_s_paths(med.h, sc.ctypes.data_as(ctypes.c_void_p), 0, 0.8, rad.data_ptr(), None) == -1
 
 
+@pytest.mark.parametrize("scheme", [2, 1, 0])
+def test_render_scene_s_nee(env, scheme):
+    """Scene S with the conductor NEE coupling (volumeLightSample + volumePhaseSample with neePDF / neeGrad) on
+    the C2 medium.  neePDF / neeGrad go through double-precision exp/log, which device and host libm round
+    differently, so the image is compared with a tolerance (1e-3 relative per pixel, 99.5 % of the pixels;
+    the sum within 1e-3) instead of bitwise."""
+    import torch
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C2")
+    params["scheme_1d"] = scheme
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    w, h, spp = 64, 64, 4
+    scene = ob.default_scene_s(w, h, spp)
+    surf = pkg.default_surface_s()
+    if scheme == 0:
+        surf["cap_cos"] = 0.9
+    want = orc.render_scene_s_nee(scene, surf)
+    rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+    sc = np.array(scene, dtype=pkg.SCENE_S)
+    sf = np.array(surf, dtype=pkg.SURFACE_S)
+    med.call("gpis_render_scene_s_nee", sc.ctypes.data_as(ctypes.c_void_p), sf.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), stream_ptr())
+    torch.cuda.synchronize()
+    got = rad.cpu().numpy().reshape(h, w)
+    assert want.sum() > 0
+    close = np.isclose(got, want, rtol=1e-3, atol=1e-6)
+    print("scheme %d: sum gpu %.6f oracle %.6f, pixels outside tolerance %d, bitwise equal %d of %d" % (
+        scheme, got.sum(), want.sum(), (~close).sum(), (got == want).sum(), got.size))
+    assert close.mean() >= 0.995
+    assert abs(float(got.sum()) - float(want.sum())) <= 1e-3 * float(want.sum())
+    bad = np.array(surf, dtype=pkg.SURFACE_S)
+    bad["cap_cos"] = 1.0
+    assert med.L.lib.gpis_render_scene_s_nee(med.h, sc.ctypes.data_as(ctypes.c_void_p), bad.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None) == -1
+
+
 def test_error_behaviour(env):
     pkg, ob, lib = env
     bad = pkg.params_for_config("C0")
