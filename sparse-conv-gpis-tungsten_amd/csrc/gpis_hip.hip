@@ -270,6 +270,9 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
 // kernels — generic path: one lane = one ray / query, impulses generated on the fly
 // ======================================================================================
 constexpr int kBlock = 64;   // one wave per workgroup: rays are independent, small blocks balance the march
+#ifndef GPIS_GENERIC_OCC
+#define GPIS_GENERIC_OCC 4   // waves per SIMD the lane-per-ray march kernels are register-allocated for (C2 scene S: 1 wave 11.6, 2 → 20.4, 3 → 25.2, 4 → 26.6, 5 → 26.0 Msamples/s)
+#endif
 
 __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t n_eval, uint32_t n_seg)
 {
@@ -285,7 +288,9 @@ __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t n_eval, u
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_sample_distance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+// P = the path instance (gpis_device.hpp: generic / spec_1d / spec_3d / spec_3d_multires)
+template <class P>
+__global__ void __launch_bounds__(kBlock, GPIS_GENERIC_OCC) k_sample_distance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
                                                             gpis_seg_out *__restrict__ out, gpis_cond_coeff *__restrict__ coeff,
                                                             const uint8_t *__restrict__ mask, Counters *cnt)
 {
@@ -296,7 +301,7 @@ __global__ void __launch_bounds__(kBlock) k_sample_distance(const DevModel *__re
     if (i < n && (!mask || mask[i])) {
         gpis_ray_in ray = rays[i];
         gpis_seg_out o;
-        sample_distance_one(M, noise, ray, o);
+        P::sample_distance(M, noise, ray, o);
         out[i] = o;
         if (coeff) {
             gpis_cond_coeff c = noise.c;
@@ -308,7 +313,8 @@ __global__ void __launch_bounds__(kBlock) k_sample_distance(const DevModel *__re
     flush_counters(cnt, noise.n_eval, nseg);
 }
 
-__global__ void __launch_bounds__(kBlock) k_transmittance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
+template <class P>
+__global__ void __launch_bounds__(kBlock, GPIS_GENERIC_OCC) k_transmittance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
                                                           uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
 {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -320,7 +326,7 @@ __global__ void __launch_bounds__(kBlock) k_transmittance(const DevModel *__rest
             gpis_ray_in ray = rays[i];
             MediumState st;
             state_from_ray(ray, st);
-            visible[i] = transmittance_one(M, noise, ray, st) ? 1 : 0;
+            visible[i] = P::transmittance(M, noise, ray, st) ? 1 : 0;
             nseg = 1;
         } else {
             visible[i] = 0;
@@ -1035,7 +1041,17 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
         if (st != GPIS_OK) return set_err(st, "fast sample_distance launch failed");
         return launch_check("k_fast_sample_distance");
     }
-    k_sample_distance<<<grid_of(n, kBlock), kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
+    // pick the instance whose compile-time flags equal the medium's
+    const DevModel &H = m->host_model;
+    const unsigned grid = grid_of(n, kBlock);
+    if (H.sampling_1d)
+        k_sample_distance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
+    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid)
+        k_sample_distance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
+    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
+        k_sample_distance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
+    else
+        k_sample_distance<generic::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
     return launch_check("k_sample_distance");
 }
 static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible, const uint8_t *mask, hipStream_t s)
@@ -1051,7 +1067,16 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
         if (st != GPIS_OK) return set_err(st, "fast transmittance launch failed");
         return launch_check("k_fast_transmittance");
     }
-    k_transmittance<<<grid_of(n, kBlock), kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
+    const DevModel &H = m->host_model;
+    const unsigned grid = grid_of(n, kBlock);
+    if (H.sampling_1d)
+        k_transmittance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
+    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid)
+        k_transmittance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
+    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
+        k_transmittance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
+    else
+        k_transmittance<generic::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
     return launch_check("k_transmittance");
 }
 
