@@ -2243,6 +2243,10 @@ int oracle_render_scene_s_nee(oracle_medium *m, const gpis_scene_s *s, const gpi
 /* ======================================================================================
  * Pinning surface
  * ==================================================================================== */
+float oracle_conductor_reflectance(float eta, float k, float cosThetaI) { return conductor_reflectance(eta, k, cosThetaI); }
+float oracle_power_heuristic(float pdf0, float pdf1) { return power_heuristic(pdf0, pdf1); }
+float oracle_spherical_cap_pdf(float cosThetaMax) { return (0.5f * INV_PI_F) / (1.0f - cosThetaMax); }
+
 
 void oracle_cell3d_draws(uint64_t state, uint32_t k, float *out)
 {

@@ -81,6 +81,9 @@ void oracle_eig_second_deriv_inv(const float *m9, float *out9);
 void oracle_eig_scaled_matmul(float amplitude, const float *a9, const float *b9, float *out9);
 void oracle_eig_gram(const float *w9, float *out9, float *det);
 void oracle_eig_scale_and_inverse(float l_conv, const float *a9, float *l2w9, float *w2l9);
+float oracle_conductor_reflectance(float eta, float k, float cosThetaI);
+float oracle_power_heuristic(float pdf0, float pdf1);
+float oracle_spherical_cap_pdf(float cosThetaMax);
 void oracle_eig_invcov_scale(const float *m9, float globalScale, float localScale, int isCov, float *out9);
 
 #ifdef __cplusplus

@@ -15,6 +15,8 @@
 //   * TangentFrame (Duff ONB)          (src/core/math/TangentFrame.hpp:63-107)
 //   * rand_normal_2 / sample_standard_normal (src/core/sampling/Gaussian.cpp:21-34, 87-103)
 //   * Vec3f length/normalized/dot      (src/core/math/Vec.hpp:134-206)
+//   * Fresnel::conductorReflectance    (src/core/bsdfs/Fresnel.hpp:102-123)
+//   * SampleWarp::powerHeuristic, uniformSphericalCapPdf (src/core/sampling/SampleWarp.hpp:131-134, 189-192)
 //   * the Eigen expression FORMS the path uses (evaluation order of 3-term sums, 3x3
 //     inverse), evaluated with the reference's vendored Eigen under the reference's flags.
 #include "math/MathUtil.hpp"
@@ -24,6 +26,8 @@
 #include "math/Angle.hpp"
 #include "sampling/UniformSampler.hpp"
 #include "sampling/Gaussian.hpp"
+#include "sampling/SampleWarp.hpp"
+#include "bsdfs/Fresnel.hpp"
 
 #include <Eigen/Dense>
 #include <cstdint>
@@ -235,5 +239,9 @@ void ref_eig_invcov_scale(const float *m, float globalScale, float localScale, i
     storeM(M, out);
 }
 float ref_pi_float(void) { return PI; }
+float ref_conductor_reflectance(float eta, float k, float cosThetaI) { return Fresnel::conductorReflectance(eta, k, cosThetaI); }
+float ref_power_heuristic(float pdf0, float pdf1) { return SampleWarp::powerHeuristic(pdf0, pdf1); }
+float ref_uniform_spherical_cap_pdf(float cosThetaMax) { return SampleWarp::uniformSphericalCapPdf(cosThetaMax); }
+float ref_inv_pi_float(void) { return INV_PI; }
 
 } // extern "C"

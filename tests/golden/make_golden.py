@@ -65,6 +65,18 @@ def ref_primitives():
     for i, n in enumerate(ns):
         ref.ref_tangent_frame(P(n), P(frames[i]))
     out.update(frame_in=ns, frame_out=frames)
+    # Fresnel.hpp:102-123 and SampleWarp.hpp:131-134, 189-192 (the conductor NEE estimator's arithmetic);
+    # generated after everything above so the earlier vectors keep their random draws
+    for n, k in (("ref_conductor_reflectance", 3), ("ref_power_heuristic", 2), ("ref_uniform_spherical_cap_pdf", 1)):
+        getattr(ref, n).restype = ctypes.c_float
+        getattr(ref, n).argtypes = [ctypes.c_float] * k
+    fr_in = np.column_stack([rng.choice([0.2, 1.5, 0.0, 2.9, 0.05], 256), rng.choice([3.9, 0.0, 3.1, 7.0], 256), rng.uniform(-1, 1, 256)]).astype(f32)
+    fr_in[:3] = [[0, 0, 0.5], [0.2, 3.9, 1.0], [0.2, 3.9, 0.0]]
+    out.update(fresnel_in=fr_in, fresnel_out=np.array([ref.ref_conductor_reflectance(*map(float, r)) for r in fr_in], dtype=f32))
+    ph_in = rng.uniform(0, 50, (256, 2)).astype(f32)
+    out.update(power_heuristic_in=ph_in, power_heuristic_out=np.array([ref.ref_power_heuristic(*map(float, r)) for r in ph_in], dtype=f32))
+    cap_in = rng.uniform(-0.99, 0.9999, 128).astype(f32)
+    out.update(cap_pdf_in=cap_in, cap_pdf_out=np.array([ref.ref_uniform_spherical_cap_pdf(float(c)) for c in cap_in], dtype=f32))
     np.savez_compressed(os.path.join(HERE, "ref_primitives.npz"), **out)
 
 

@@ -37,6 +37,12 @@ def test_reference_primitive_vectors(ob):
         got = np.zeros(9, dtype=f32)
         L.oracle_tangent_frame(P(np.ascontiguousarray(n)), P(got))
         assert np.array_equal(got, want)
+    for n, k in (("oracle_conductor_reflectance", 3), ("oracle_power_heuristic", 2), ("oracle_spherical_cap_pdf", 1)):
+        getattr(L, n).restype = ctypes.c_float
+        getattr(L, n).argtypes = [ctypes.c_float] * k
+    assert np.array_equal(np.array([L.oracle_conductor_reflectance(*map(float, r)) for r in g["fresnel_in"]], dtype=f32), g["fresnel_out"])
+    assert np.array_equal(np.array([L.oracle_power_heuristic(*map(float, r)) for r in g["power_heuristic_in"]], dtype=f32), g["power_heuristic_out"])
+    assert np.array_equal(np.array([L.oracle_spherical_cap_pdf(float(c)) for c in g["cap_pdf_in"]], dtype=f32), g["cap_pdf_out"])
 
 
 def test_reference_kat_file(pkg, ob):

@@ -153,3 +153,24 @@ def test_eigen_expression_forms(libs):
             orc.oracle_eig_invcov_scale(P(M), ctypes.c_float(1.7), ctypes.c_float(0.6), is_cov, P(x))
             ref.ref_eig_invcov_scale(P(M), ctypes.c_float(1.7), ctypes.c_float(0.6), is_cov, P(y))
             assert np.array_equal(x, y)
+
+
+def test_fresnel_and_mis_weights(libs):
+    """Arithmetic of the conductor NEE estimator against the reference's own
+    Fresnel.hpp / SampleWarp.hpp."""
+    orc, ref, ob = libs
+    for lib, names in ((orc, ("oracle_conductor_reflectance", "oracle_power_heuristic", "oracle_spherical_cap_pdf")),
+                       (ref, ("ref_conductor_reflectance", "ref_power_heuristic", "ref_uniform_spherical_cap_pdf"))):
+        for n in names:
+            fn = getattr(lib, n)
+            fn.restype = ctypes.c_float
+            fn.argtypes = [ctypes.c_float] * (3 if "reflectance" in n else (2 if "heuristic" in n else 1))
+    bits = lambda v: np.float32(v).view(np.uint32)
+    rng = np.random.default_rng(5)
+    for eta, k in ((0.2, 3.9), (1.5, 0.0), (0.0, 0.0), (2.9, 3.1), (0.05, 7.0)):
+        for c in np.concatenate([rng.uniform(-1, 1, 400), [0.0, 1.0, -1.0, 1e-6, 0.999999]]).astype(f32):
+            assert bits(orc.oracle_conductor_reflectance(eta, k, float(c))) == bits(ref.ref_conductor_reflectance(eta, k, float(c))), (eta, k, c)
+    for a, b in rng.uniform(0, 50, (2000, 2)).astype(f32):
+        assert bits(orc.oracle_power_heuristic(float(a), float(b))) == bits(ref.ref_power_heuristic(float(a), float(b)))
+    for c in rng.uniform(-0.99, 0.9999, 500).astype(f32):
+        assert bits(orc.oracle_spherical_cap_pdf(float(c))) == bits(ref.ref_uniform_spherical_cap_pdf(float(c)))
