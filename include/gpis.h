@@ -224,9 +224,9 @@ typedef struct gpis_derived {
     float local_to_world[9];
     float kernel_radius_world; /* splattingKernelRadius(false, 1) */
     float kernel_radius_iso;   /* splattingKernelRadius(true, 1)  */
-    float norm3d_world;        /* sqrt(sparseConvNoiseVariance3D(world)) at scale 1 */
-    float norm3d_iso;          /* sqrt(sparseConvNoiseVariance3D(iso)) */
-    float norm1d;              /* sqrt(sparseConvNoiseVariance1D) */
+    float norm3d_world;        /* sqrt(sparseConvNoiseVariance3D(world)) at scale 1; 0 for non-stationary media (position dependent) */
+    float norm3d_iso;          /* sqrt(sparseConvNoiseVariance3D(iso)); 0 for non-stationary media */
+    float norm1d;              /* sqrt(sparseConvNoiseVariance1D); 0 for non-stationary media */
     uint32_t impulses_per_cell;
     int32_t activate_conditioning; /* SCN.cpp:21 */
     int32_t effective_scheme_1d;   /* SCN.cpp:23-26 */

@@ -1595,6 +1595,11 @@ int oracle_get_derived(const oracle_medium *m, gpis_derived *o)
     o->norm3d_world = sqrtf(cov_variance3d(m, z, m->P.impulse_density, o->kernel_radius_world, 0, cov_world_sampling_scale(m)));
     o->norm3d_iso = sqrtf(cov_variance3d(m, z, m->P.impulse_density, o->kernel_radius_iso, 1, 1.0f));
     o->norm1d = sqrtf(cov_variance1d(m, z, m->P.impulse_density, o->kernel_radius_iso));
+    if (m->P.nonstationary) {   /* position dependent: not a constant of the medium (gpis.h) */
+        o->norm3d_world = 0.f;
+        o->norm3d_iso = 0.f;
+        o->norm1d = 0.f;
+    }
     o->impulses_per_cell = m->n_impulses;
     o->activate_conditioning = m->activate_conditioning;
     o->effective_scheme_1d = m->scheme_1d_eff;

@@ -535,7 +535,7 @@ GPIS_DEV void finish_sample_distance(const DevModel &M, const gpis_ray_in *__res
     o.t = t;
     o.exited = hit ? 0 : 1;
     o.last_val = last_val;
-    o.gp_id = gp;
+    o.gp_id = hit ? gp : rayp->last_gp_id;   // intersectGP stores GPId only on a hit (SCNM.cpp:162); an exit keeps state.lastGPId
     bool ok = true;
     if (hit) {
         double avg = (aniso.x + aniso.y + aniso.z) / 3.0;

@@ -255,9 +255,7 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
         float ls = (float)((double)1.0f * (M.multi_resolution_grid ? 1.0 : (double)M.ls_maxval));
         D.kernel_radius_world = M.kernel_scale * ls * M.mtx_factor;
         D.kernel_radius_iso = M.kernel_scale;
-        float nss = M.multi_resolution_grid ? 1.0f : (float)0.f;   // position dependent when !multi_resolution_grid
-        (void)nss;
-        D.norm3d_world = 0.f; D.norm3d_iso = M.norm3d_iso; D.norm1d = 0.f;
+        D.norm3d_world = 0.f; D.norm3d_iso = 0.f; D.norm1d = 0.f;   // position dependent: not constants of the medium
     }
     D.impulses_per_cell = M.n_impulses;
     D.activate_conditioning = M.activate_conditioning;

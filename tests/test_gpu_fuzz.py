@@ -1,0 +1,138 @@
+"""Randomised configurations: the fixed configs C0-C3 exercise a handful of flag combinations; here
+seeded random parameter blocks (kernel anisotropy, means incl. linear and CSG-min pairs, sampling
+spaces, contexts, densities, step sizes, non-stationary ramps) go through both implementations.
+Expectation per case: the 3D stationary chain is bit-exact; anything that passes through double
+libm (1D gradient, length-scale ramps: DESIGN.md §2) is compared with a tolerance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _random_params(pkg, rng):
+    p = pkg.params_for_config("C0")
+    p["single_realization"] = int(rng.integers(0, 2))
+    p["isotropic_3d_sampling"] = int(rng.integers(0, 2))
+    p["sampling_1d"] = int(rng.random() < 0.3)
+    p["scheme_1d"] = int(rng.integers(0, 3))
+    p["correlation_xy"] = int(rng.integers(0, 2))
+    p["correlation_context"] = int(rng.integers(0, 4))
+    p["impulse_density"] = float(rng.choice([3.0, 8.0, 12.5, 32.0]))
+    p["seed"] = int(rng.integers(0, 2 ** 31))
+    p["sigma"] = float(rng.uniform(0.05, 0.3))
+    p["length_scale"] = float(rng.uniform(0.04, 0.12))
+    if rng.random() < 0.5:
+        p["aniso"] = rng.uniform(0.6, 1.6, 3).astype(f32)
+    if rng.random() < 0.25:
+        a = rng.uniform(-0.2, 0.2, (3, 3))
+        m = np.eye(3) + a @ a.T + 0.3 * np.diag(rng.uniform(0, 1, 3))
+        p["use_aniso_mtx"] = 1
+        p["aniso_mtx"] = m.astype(f32).reshape(9)
+    p["local_scale"] = float(rng.choice([2.0, 3.0, 4.0]))
+    p["step_size"] = float(rng.choice([0.005, 0.01, 0.02]))
+    p["min_step"] = int(rng.choice([4, 8, 16]))
+    p["max_bounces"] = int(rng.choice([2, 1024]))
+    kind = rng.integers(0, 4)
+    if kind == 1:
+        p["mean"]["type"] = pkg.MEAN_TYPE.LINEAR
+        p["mean"]["center"] = rng.uniform(-0.3, 0.3, 3)
+        p["mean"]["dir"] = rng.standard_normal(3)
+        p["mean"]["scale"] = float(rng.uniform(0.5, 2.0))
+        p["mean"]["min"] = float(rng.choice([-3.4e38, -0.2]))
+    elif kind == 2:
+        p["mean"]["type"] = pkg.MEAN_TYPE.HOMOGENEOUS
+        p["mean"]["offset"] = float(rng.uniform(-0.05, 0.1))
+    else:
+        p["mean"]["center"] = rng.uniform(-0.2, 0.2, 3)
+        p["mean"]["radius"] = float(rng.uniform(0.6, 1.1))
+    if rng.random() < 0.35:
+        p["has_mean_additional"] = 1
+        p["mean_additional"]["type"] = pkg.MEAN_TYPE.SPHERICAL
+        p["mean_additional"]["center"] = rng.uniform(-0.8, 0.8, 3)
+        p["mean_additional"]["radius"] = float(rng.uniform(0.3, 0.7))
+    if rng.random() < 0.3:
+        p["nonstationary"] = 1
+        p["multi_resolution_grid"] = int(rng.integers(0, 2))
+        p["ls_ramp_type"] = int(rng.integers(0, 3))
+        p["ls_min"], p["ls_max"] = 0.5, float(rng.choice([1.5, 2.0]))
+        p["ls_start"], p["ls_end"] = -1.0, 1.0
+    return p
+
+
+def _random_rays(ob, rng, n):
+    r = np.zeros(n, dtype=ob.RAY_IN)
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    inside = rng.random(n) < 0.4
+    o = np.where(inside[:, None], rng.uniform(-0.9, 0.9, (n, 3)), -2.5 * d + rng.uniform(-0.7, 0.7, (n, 3)))
+    r["pos"], r["dir"] = o.astype(f32), d.astype(f32)
+    r["near_t"] = np.where(inside, 0.0, rng.uniform(0.8, 1.4, n)).astype(f32)
+    r["far_t"] = r["near_t"] + rng.uniform(0.3, 2.2, n).astype(f32)
+    r["far_t"][:3] = (0.0, np.inf, r["near_t"][2])          # the early-out, the "infinite segment" and the empty segment
+    r["pixel"] = rng.integers(0, 2000, (n, 2))
+    r["spp"] = rng.integers(0, 64, n)
+    r["segment"] = rng.integers(0, 4, n)
+    r["scene_seed"] = 0xBA5EBA11
+    r["info_t"] = rng.uniform(0, 3, n).astype(f32)
+    r["u_jitter"] = rng.random(n).astype(f32)
+    r["first_scatter"] = (~inside).astype(np.uint32) if r["first_scatter"].dtype != np.bool_ else ~inside
+    r["bounce"] = np.where(inside, rng.integers(1, 3, n), 0)
+    r["last_gp_id"] = np.where(inside, rng.integers(0, 2, n), 0)
+    r["last_val"] = np.where(inside, rng.uniform(-0.02, 0.02, n), 0).astype(f32)
+    r["last_aniso"] = np.where(inside[:, None], rng.standard_normal((n, 3)) * 4.0, 0.0)
+    return r
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_configuration(pkg, ob, seed):
+    rng = np.random.default_rng(1000 + seed)
+    params = _random_params(pkg, rng)
+    try:
+        orc = ob.Oracle(params, threads=16)
+    except Exception as e_orc:
+        with pytest.raises(RuntimeError):
+            pkg.Medium(params)
+        pytest.skip("both implementations reject this block: %s" % e_orc)
+    med = pkg.Medium(params)
+    d_g, d_o = med.derived(), orc.derived()
+    for k in d_g.dtype.names:
+        if k != "fast_path":
+            assert np.array_equal(np.asarray(d_g[k]), np.asarray(d_o[k]), equal_nan=True), k
+    exact = not int(params["sampling_1d"]) and not int(params["nonstationary"])
+    rays = _random_rays(ob, rng, 448)
+    got, cg = med.sample_distance(rays, want_coeff=True)
+    want, cw = orc.sample_distance(rays, want_coeff=True)
+    vis_g, vis_o = med.transmittance(rays), orc.transmittance(rays)
+    desc = {k: (params[k].tolist() if hasattr(params[k], "tolist") else params[k]) for k in
+            ("single_realization", "isotropic_3d_sampling", "sampling_1d", "correlation_context", "nonstationary", "multi_resolution_grid", "use_aniso_mtx", "has_mean_additional")}
+    print("seed", seed, desc, "mean", int(params["mean"]["type"]), "fast", int(d_g["fast_path"]), "hits", int((want["exited"] == 0).sum()),
+          "blocked", int((vis_o == 0).sum()))
+    if exact:
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], want[f], equal_nan=True), (seed, f)
+        for f in cg.dtype.names:
+            if f != "n_evals":
+                assert np.array_equal(cg[f], cw[f], equal_nan=True), (seed, f)
+        assert np.array_equal(vis_g, vis_o)
+        if int(d_g["fast_path"]):
+            # the same block through the guided march (coarse guide: plenty of exact fall-backs) and its certificate
+            med.build_guide(8, 8)
+            got2 = med.sample_distance(rays)
+            for f in got2.dtype.names:
+                assert np.array_equal(got2[f], want[f], equal_nan=True), (seed, "guided", f)
+            assert np.array_equal(med.transmittance(rays), vis_o)
+            from gpu_util import to_dev
+            finite = rays[np.isfinite(rays["far_t"])]
+            d = to_dev(finite)
+            certified, bad = med.guide_raycheck(d.data_ptr(), len(finite), 300)
+            print("   guided: %d certified steps, %d violations" % (certified, bad))
+            assert bad == 0
+    else:
+        same = (got["exited"] == want["exited"]) & (got["ok"] == want["ok"])
+        assert same.mean() >= 0.99, (seed, same.mean())
+        for f in ("t", "sample_t", "p", "aniso", "last_val"):
+            a, b = np.asarray(got[f])[same], np.asarray(want[f])[same]
+            close = np.isclose(a, b, rtol=5e-4, atol=5e-5, equal_nan=True)
+            assert close.mean() >= 0.99, (seed, f, close.mean())
+        assert (vis_g == vis_o).mean() >= 0.99
