@@ -351,6 +351,27 @@ class Medium:
                      "gpis_eval_gradient_host")
         return g
 
+    def conditioning(self, q, target_val, target_grad):
+        q = np.ascontiguousarray(q, dtype=QUERY)
+        tv = np.ascontiguousarray(target_val, dtype=np.float32)
+        tg = np.ascontiguousarray(target_grad, dtype=np.float32)
+        co = np.zeros(q.shape[0], dtype=COND_COEFF)
+        self.L.check(self.L.lib.gpis_conditioning_host(self.h, q.shape[0], _ptr(q), _ptr(tv), _ptr(tg), _ptr(co)),
+                     "gpis_conditioning_host")
+        return co
+
+    def nee_pdf(self, q):
+        q = np.ascontiguousarray(q, dtype=NEE_QUERY)
+        out = np.zeros(q.shape[0], dtype=np.float32)
+        self.L.check(self.L.lib.gpis_nee_pdf_host(self.h, q.shape[0], _ptr(q), _ptr(out)), "gpis_nee_pdf_host")
+        return out
+
+    def nee_grad(self, q):
+        q = np.ascontiguousarray(q, dtype=NEE_QUERY)
+        out = np.zeros((q.shape[0], 3), dtype=np.float32)
+        self.L.check(self.L.lib.gpis_nee_grad_host(self.h, q.shape[0], _ptr(q), _ptr(out)), "gpis_nee_grad_host")
+        return out
+
     def counters(self):
         e = ctypes.c_uint64()
         s = ctypes.c_uint64()

@@ -100,6 +100,32 @@ def test_random_configuration(pkg, ob, seed):
         if k != "fast_path":
             assert np.array_equal(np.asarray(d_g[k]), np.asarray(d_o[k]), equal_nan=True), k
     exact = not int(params["sampling_1d"]) and not int(params["nonstationary"])
+    # single-point entries: evaluateValue / evaluateGradient under random conditioning coefficients
+    q = np.zeros(256, dtype=pkg.QUERY)
+    q["p"] = rng.uniform(-1.3, 1.3, (256, 3)).astype(f32)
+    qd = rng.standard_normal((256, 3))
+    q["dir"] = (qd / np.linalg.norm(qd, axis=1, keepdims=True)).astype(f32)
+    q["t_segment"] = rng.uniform(0, 2, 256).astype(f32)
+    q["info_t"] = rng.uniform(0, 3, 256).astype(f32)
+    q["pixel"] = rng.integers(0, 1920, (256, 2))
+    q["spp"] = rng.integers(0, 64, 256)
+    q["segment"] = rng.integers(0, 4, 256)
+    q["scene_seed"] = 0xBA5EBA11
+    tv = rng.uniform(-0.05, 0.05, 256).astype(f32)
+    tg = (rng.standard_normal((256, 3)) * 3).astype(f32)
+    c_g, c_o = med.conditioning(q, tv, tg), orc.conditioning(q, tv, tg)
+    q["coeff"] = c_o
+    (v_g, id_g), (v_o, id_o) = med.eval_value(q), orc.eval_value(q)
+    g_g, g_o = med.eval_gradient(q), orc.eval_gradient(q)
+    assert np.array_equal(id_g, id_o)
+    if exact:
+        for f in c_g.dtype.names:
+            if f != "n_evals":
+                assert np.array_equal(c_g[f], c_o[f], equal_nan=True), (seed, "coeff", f)
+        assert np.array_equal(v_g, v_o, equal_nan=True) and np.array_equal(g_g, g_o, equal_nan=True), seed
+    else:
+        assert np.isclose(v_g, v_o, rtol=5e-4, atol=5e-5, equal_nan=True).mean() >= 0.99
+        assert np.isclose(g_g, g_o, rtol=5e-4, atol=5e-4, equal_nan=True).mean() >= 0.99
     rays = _random_rays(ob, rng, 448)
     got, cg = med.sample_distance(rays, want_coeff=True)
     want, cw = orc.sample_distance(rays, want_coeff=True)
