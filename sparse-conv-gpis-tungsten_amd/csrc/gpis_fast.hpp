@@ -381,6 +381,8 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
 // which is the reference's order (SCN.cpp:383-392), and cells in dx,dy,dz order (SCN.cpp:368-371).
 // ~2.4k instructions per query against ~10k for a cooperative evaluation: used when only a few lanes
 // of a wave need an exact value.  The result is wave-uniform.
+// (Packing two cells per pass at rho <= 32 halves the passes but its extra live values cost the guided
+// kernels 32 B/lane of scratch and 5 % of their time: measured and not done.)
 GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds &lds, int src, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
 {
     const int lane = (int)(threadIdx.x & 63);
