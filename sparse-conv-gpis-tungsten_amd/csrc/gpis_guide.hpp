@@ -315,11 +315,23 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
     float step_size = (farT - nearT) / (float)M.min_step;
     if (M.step_size < step_size)
         step_size = M.step_size;
-    Frame coord{};
-    if (M.iso3d)
-        coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
-
-    const GuideRay gr = guide_ray(M, F, pos, dir, coord);
+    // The ray's isotropic-ray frame (SCN.cpp:296-297) is needed by the exact evaluations only; it is
+    // re-derived from `dir` there instead of being kept live across the march (9 VGPRs of a kernel
+    // that spills).  The empty asm hides the loop invariance from LICM, which would hoist it back.
+    auto ray_frame = [&]() {
+        Frame c{};
+        if (M.iso3d) {
+            V3 d = dir;
+            asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
+            c = frame_from_normal(normalized(cov_pos_w2l(M, d, 1.0f)));
+        }
+        return c;
+    };
+    GuideRay gr;
+    {
+        const Frame coord = ray_frame();
+        gr = guide_ray(M, F, pos, dir, coord);
+    }
     int phase = G_INIT;
     bool early_ok = false;
     if (!valid)
@@ -433,6 +445,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
             break;
         const double tq = phase == X_F0 ? (double)nearT : (phase == X_PREV ? t_prevpos : (phase == X_REFINE ? t_test : (phase == X_FINAL ? (double)farT : t)));
         const V3 pq = world_at(tq);
+        const Frame coord = ray_frame();
         const V3 ug = grid_point(M, F, pq, coord);
         const int cx = (int)floorf(ug.x), cy = (int)floorf(ug.y), cz = (int)floorf(ug.z);
         const int lead = __builtin_ctzll(need_mask);
@@ -517,6 +530,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         V3d rdn = to_d(dir);
         { double inv = 1.0 / length_d(rdn); rdn.x *= inv; rdn.y *= inv; rdn.z *= inv; }
         const V3 pgq = to_f(ray_at(to_d(pos), rdn, t));
+        const Frame coord = ray_frame();
         const V3 ug = grid_point(M, F, pgq, coord);
         const int cx = (int)floorf(ug.x), cy = (int)floorf(ug.y), cz = (int)floorf(ug.z);
         bool pending = want_grad;
