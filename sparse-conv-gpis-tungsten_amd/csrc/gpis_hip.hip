@@ -264,6 +264,11 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
     return GPIS_OK;
 }
 
+namespace gpis {
+hipError_t sort_pairs_u32(void *temp, size_t &temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
+                          const uint32_t *vals_in, uint32_t *vals_out, size_t n, hipStream_t stream);   // gpis_sort.hip
+}
+
 // ======================================================================================
 // kernels — generic path: one lane = one ray / query, impulses generated on the fly
 // ======================================================================================
@@ -583,18 +588,77 @@ __global__ void __launch_bounds__(256) k_paths_begin(SceneConst sc, size_t first
     a.alive[i] = hit ? 1 : 0;
 }
 
-// after sampleDistance of segment `bounce`: next-event estimation set-up + the bounce itself
-__global__ void __launch_bounds__(256) k_paths_shade(SceneConst sc, size_t n_samples, int bounce, int max_bounces, float albedo, PathArrays a)
+// Regrouping of a bounce's segments (k_paths_keys → radix sort → k_paths_gather).  Key = Morton code of
+// the lattice cell the segment starts in, computed in the space the medium's grid lives in: in
+// isotropic-ray space every ray travels along the lattice's +z axis (SCN.cpp:296-301: the frame's normal
+// is the whitened direction), so segments that start in the same lattice cell stay neighbours for
+// their whole length, whatever their world-space directions; in world space the direction octant is
+// appended.  Dead paths get the largest key: the sort is also the compaction.
+__device__ __forceinline__ uint32_t spread3(uint32_t v)   // 9 bits -> every third bit
+{
+    v &= 0x1FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ void __launch_bounds__(256) k_paths_keys(const DevModel *__restrict__ Mp, float cell_size, size_t n, const gpis_ray_in *__restrict__ rays,
+                                                    const uint8_t *__restrict__ alive, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_samples) return;
+    if (i >= n) return;
+    uint32_t key = 0xFFFFFFFFu;
+    if (alive[i]) {
+        const DevModel &M = *Mp;
+        const V3 p = v3(rays[i].pos[0], rays[i].pos[1], rays[i].pos[2]);
+        const V3 d = v3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+        V3 u = p;
+        if (M.iso3d) {
+            const Frame coord = frame_from_normal(normalized(cov_pos_w2l(M, d, 1.0f)));
+            u = to_local(coord, cov_pos_w2l(M, p, 1.0f));
+        }
+        const float inv = 1.0f / cell_size;
+        const int cx = (int)floorf(fminf(fmaxf(u.x * inv, -255.f), 255.f)) + 256;
+        const int cy = (int)floorf(fminf(fmaxf(u.y * inv, -255.f), 255.f)) + 256;
+        const int cz = (int)floorf(fminf(fmaxf(u.z * inv, -255.f), 255.f)) + 256;
+        const uint32_t morton = (spread3((uint32_t)cx) << 2) | (spread3((uint32_t)cy) << 1) | spread3((uint32_t)cz);
+        const uint32_t oct = M.iso3d ? 0u : ((d.x < 0.f ? 4u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 1u : 0u));
+        key = (morton << 3) | oct;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(256) k_paths_gather(size_t n, const uint32_t *__restrict__ keys_sorted, const uint32_t *__restrict__ order,
+                                                      const gpis_ray_in *__restrict__ rays, gpis_ray_in *__restrict__ rays_sorted,
+                                                      uint8_t *__restrict__ live_sorted)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const bool live = keys_sorted[j] != 0xFFFFFFFFu;
+    live_sorted[j] = live ? 1 : 0;
+    if (live)
+        rays_sorted[j] = rays[order[j]];
+}
+
+// after sampleDistance of segment `bounce`: next-event estimation set-up + the bounce itself.
+// Slot j of the batch (seg, shadow, nee, contrib, vis, and rays_in) belongs to path i = order[j]
+// (identity when order is null); the path state (rng, throughput, emission, alive, next ray) is
+// indexed by i.
+__global__ void __launch_bounds__(256) k_paths_shade(SceneConst sc, size_t n_samples, int bounce, int max_bounces, float albedo, PathArrays a,
+                                                     const uint32_t *__restrict__ order, const gpis_ray_in *__restrict__ rays_in,
+                                                     const uint8_t *__restrict__ live)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_samples) return;
     uint8_t nee = 0;
-    if (!a.alive[i]) { a.nee[i] = 0; return; }
-    const gpis_seg_out o = a.seg[i];
-    if (!o.ok) { a.alive[i] = 0; a.nee[i] = 0; return; }
+    if (live ? !live[j] : !a.alive[j]) { a.nee[j] = 0; return; }
+    const size_t i = order ? (size_t)order[j] : j;
+    const gpis_seg_out o = a.seg[j];
+    if (!o.ok) { a.alive[i] = 0; a.nee[j] = 0; return; }
     float thr = a.throughput[i] * o.weight[0];
-    if (o.exited) { a.alive[i] = 0; a.nee[i] = 0; a.throughput[i] = thr; return; }
-    const gpis_ray_in ray = a.rays[i];
+    if (o.exited) { a.alive[i] = 0; a.nee[j] = 0; a.throughput[i] = thr; return; }
+    const gpis_ray_in ray = rays_in[j];
     Pcg32 g;
     g.state = a.rng[i];
     const V3 l = v3(sc.light[0], sc.light[1], sc.light[2]);
@@ -628,13 +692,13 @@ __global__ void __launch_bounds__(256) k_paths_shade(SceneConst sc, size_t n_sam
                 sh.far_t = t1;
                 sh.segment = (uint32_t)bounce + 1;
                 sh.u_jitter = normalized_uint(g.next_i());
-                a.shadow[i] = sh;
-                a.contrib[i] = thr * (f * sc.s.light_radiance);
+                a.shadow[j] = sh;
+                a.contrib[j] = thr * (f * sc.s.light_radiance);
                 nee = 1;
             }
         }
     }
-    a.nee[i] = nee;
+    a.nee[j] = nee;
     bool alive = wi.z > 0.0f;
     if (alive) {
         float dx, dy, d2;
@@ -661,12 +725,16 @@ __global__ void __launch_bounds__(256) k_paths_shade(SceneConst sc, size_t n_sam
     a.rng[i] = g.state;
 }
 
-__global__ void __launch_bounds__(256) k_paths_nee_add(size_t n_samples, PathArrays a)
+// slot k of the (possibly regrouped) shadow batch -> slot j of the bounce batch -> path i
+__global__ void __launch_bounds__(256) k_paths_nee_add(size_t n_samples, PathArrays a, const uint32_t *__restrict__ order,
+                                                       const uint32_t *__restrict__ shadow_order, const uint8_t *__restrict__ shadow_live,
+                                                       const uint8_t *__restrict__ vis)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_samples) return;
-    if (a.nee[i])
-        a.emission[i] += a.vis[i] ? a.contrib[i] : 0.f;
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_samples) return;
+    if (shadow_order ? !shadow_live[k] : !a.nee[k]) return;
+    const size_t j = shadow_order ? (size_t)shadow_order[k] : k;
+    a.emission[order ? (size_t)order[j] : j] += vis[k] ? a.contrib[j] : 0.f;
 }
 
 __global__ void __launch_bounds__(256) k_paths_accumulate(uint32_t spp, size_t first_pixel, size_t n_pixels, const float *__restrict__ emission,
@@ -1504,9 +1572,27 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
     size_t o_rays = carve(ns_max * sizeof(gpis_ray_in)), o_seg = carve(ns_max * sizeof(gpis_seg_out)), o_sh = carve(ns_max * sizeof(gpis_ray_in));
     size_t o_rng = carve(ns_max * 8), o_thr = carve(ns_max * 4), o_em = carve(ns_max * 4), o_con = carve(ns_max * 4);
     size_t o_alive = carve(ns_max), o_nee = carve(ns_max), o_vis = carve(ns_max);
+    // regrouping of secondary segments (GPIS_PATHS_SORT=0 keeps the sample order: results are identical)
+    const char *sort_env = getenv("GPIS_PATHS_SORT");
+    const bool regroup = !(sort_env && sort_env[0] == '0') && max_path_bounces > 2;
+    size_t sort_temp_bytes = 0;
+    size_t o_keys = 0, o_vals = 0, o_keys2 = 0, o_order = 0, o_rsorted = 0, o_live = 0, o_temp = 0, o_order2 = 0, o_live2 = 0;
+    if (regroup) {
+        if (sort_pairs_u32(nullptr, sort_temp_bytes, nullptr, nullptr, nullptr, nullptr, ns_max, st) != hipSuccess)
+            return set_err(GPIS_ERR_DEVICE, "radix sort scratch query failed");
+        o_keys = carve(ns_max * 4); o_vals = carve(ns_max * 4); o_keys2 = carve(ns_max * 4); o_order = carve(ns_max * 4);
+        o_rsorted = carve(ns_max * sizeof(gpis_ray_in)); o_live = carve(ns_max); o_temp = carve(sort_temp_bytes);
+        o_order2 = carve(ns_max * 4); o_live2 = carve(ns_max);
+    }
     int rc = ensure_stage(m, 3, off);
     if (rc) return rc;
     char *ws = (char *)m->stage[3];
+    uint32_t *keys = (uint32_t *)(ws + o_keys), *vals = (uint32_t *)(ws + o_vals), *keys2 = (uint32_t *)(ws + o_keys2), *order = (uint32_t *)(ws + o_order);
+    gpis_ray_in *rays_sorted = (gpis_ray_in *)(ws + o_rsorted);
+    uint8_t *live_sorted = (uint8_t *)(ws + o_live), *live2 = (uint8_t *)(ws + o_live2);
+    uint32_t *order2 = (uint32_t *)(ws + o_order2);
+    const DevModel &H = m->host_model;
+    const float cell_size = H.iso3d ? (H.radius_iso > 0.f ? H.radius_iso : H.kernel_scale) : (H.radius_world > 0.f ? H.radius_world : 0.1f);
     PathArrays a;
     a.rays = (gpis_ray_in *)(ws + o_rays); a.seg = (gpis_seg_out *)(ws + o_seg); a.shadow = (gpis_ray_in *)(ws + o_sh);
     a.rng = (uint64_t *)(ws + o_rng);
@@ -1520,11 +1606,36 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
         // the segment of bounce max-1 cannot contribute (no NEE there, TraceBase.cpp:546, and the
         // light is a Dirac delta), so it is not traced
         for (int bounce = 0; bounce + 1 < max_path_bounces; ++bounce) {
-            if ((rc = sample_distance_impl(m, ns, a.rays, a.seg, nullptr, a.alive, st))) return rc;
-            k_paths_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, ns, bounce, max_path_bounces, albedo, a);
+            // primary segments are coherent as generated (consecutive spp of a pixel); later ones are regrouped
+            const bool sorted = regroup && bounce > 0;
+            // src rays + mask -> order, regrouped copy, live flags of the regrouped slots
+            auto regroup_batch = [&](const gpis_ray_in *src, const uint8_t *mask, uint32_t *ord, gpis_ray_in *dst, uint8_t *live_out) -> int {
+                k_paths_keys<<<grid_of(ns, 256), 256, 0, st>>>(m->d_model, cell_size, ns, src, mask, keys, vals);
+                int r = launch_check("k_paths_keys");
+                if (r) return r;
+                size_t tb = sort_temp_bytes;
+                if (sort_pairs_u32(ws + o_temp, tb, keys, keys2, vals, ord, ns, st) != hipSuccess)
+                    return set_err(GPIS_ERR_DEVICE, "radix sort failed");
+                k_paths_gather<<<grid_of(ns, 256), 256, 0, st>>>(ns, keys2, ord, src, dst, live_out);
+                return launch_check("k_paths_gather");
+            };
+            if (sorted && (rc = regroup_batch(a.rays, a.alive, order, rays_sorted, live_sorted))) return rc;
+            const gpis_ray_in *rays_in = sorted ? rays_sorted : a.rays;
+            const uint8_t *live = sorted ? live_sorted : a.alive;
+            if ((rc = sample_distance_impl(m, ns, rays_in, a.seg, nullptr, live, st))) return rc;
+            k_paths_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, ns, bounce, max_path_bounces, albedo, a, sorted ? order : nullptr, rays_in,
+                                                           sorted ? live_sorted : nullptr);
             if ((rc = launch_check("k_paths_shade"))) return rc;
-            if ((rc = transmittance_impl(m, ns, a.shadow, a.vis, a.nee, st))) return rc;
-            k_paths_nee_add<<<grid_of(ns, 256), 256, 0, st>>>(ns, a);
+            if (sorted) {
+                // the shadow segments share one direction but start where the bounce segments ended: regroup
+                // them by their own lattice cells (the bounce batch's copy of the rays is free again)
+                if ((rc = regroup_batch(a.shadow, a.nee, order2, rays_sorted, live2))) return rc;
+                if ((rc = transmittance_impl(m, ns, rays_sorted, a.vis, live2, st))) return rc;
+                k_paths_nee_add<<<grid_of(ns, 256), 256, 0, st>>>(ns, a, order, order2, live2, a.vis);
+            } else {
+                if ((rc = transmittance_impl(m, ns, a.shadow, a.vis, a.nee, st))) return rc;
+                k_paths_nee_add<<<grid_of(ns, 256), 256, 0, st>>>(ns, a, nullptr, nullptr, nullptr, a.vis);
+            }
             if ((rc = launch_check("k_paths_nee_add"))) return rc;
         }
         k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(s->spp_count, first_pixel0 + p0, np, a.emission, radiance_sum);

@@ -477,6 +477,16 @@ def test_render_scene_s_paths(env, path):
         torch.cuda.synchronize()
         got = rad.cpu().numpy().reshape(h, w)
         assert np.array_equal(got, want), (cfg, np.abs(got - want).max())
+        # the regrouping of secondary segments (lattice-space sort + compaction) changes no result
+        import os
+        os.environ["GPIS_PATHS_SORT"] = "0"
+        try:
+            rad.zero_()
+            med.call("gpis_render_scene_s_paths", sc.ctypes.data_as(ctypes.c_void_p), bounces, 0.8, rad.data_ptr(), stream_ptr())
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["GPIS_PATHS_SORT"]
+        assert np.array_equal(rad.cpu().numpy().reshape(h, w), want), cfg
         # more bounces only add light
         assert (want >= single).all() and want.sum() > single.sum() > 0
     # one bounce = no next-event estimation at all (TraceBase.cpp:546): a black image

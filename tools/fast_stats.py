@@ -24,7 +24,11 @@ if len(sys.argv) > 5 and sys.argv[5] != "off":
     half, ppc = (int(x) for x in sys.argv[5].split(":"))
     med.build_guide(half, ppc)
 rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
-med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, None)
+paths_bounces = int(os.environ.get("STATS_PATHS_BOUNCES", "0"))     # > 0: the multi-bounce driver instead of scene S
+if paths_bounces:
+    med.call("gpis_render_scene_s_paths", scene.ctypes.data_as(ctypes.c_void_p), paths_bounces, 0.8, rad.data_ptr(), None)
+else:
+    med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, None)
 torch.cuda.synchronize()
 out = (ctypes.c_uint64 * 32)()
 lib.lib.gpis_debug_fast_stats(out)
