@@ -24,3 +24,13 @@ def ob():
     import oracle_bindings
     oracle_bindings.build()
     return oracle_bindings
+
+
+@pytest.fixture(autouse=True)
+def _clean_kernel_selection_env():
+    """The library reads its kernel-selection overrides from the environment at call time; a test that sets
+    one must not leak it into the next."""
+    keys = ("GPIS_MARCH", "GPIS_WAVE_TAIL", "GPIS_PATHS_SORT", "GPIS_PATHS_PRESORT")
+    yield
+    for k in keys:
+        os.environ.pop(k, None)

@@ -86,7 +86,7 @@ def test_eval_value_gradient_bit_exact(env, cfg):
     assert e_g >= 2 * len(q)
 
 
-PATHS = ["fast", "fast_gen", "fast_small_table", "generic", "guided_coarse", "guided_fine_partial"]
+PATHS = ["fast", "fast_gen", "fast_small_table", "generic", "guided_coarse", "guided_fine_partial", "guided_wave", "guided_wave_tail0"]
 
 
 def _medium(pkg, params, path):
@@ -99,8 +99,17 @@ def _medium(pkg, params, path):
       guided_coarse    guided march, guide field over the whole scene at 8 points per cell (loose
                        bound: many steps fall back to the exact evaluation)
       guided_fine_partial  guided march, 32 points per cell but only |u| < 6 cells tabulated: rays
-                       leave and re-enter the tabulated volume"""
+                       leave and re-enter the tabulated volume
+      guided_wave      the wavefront form of the guided march (state in HBM, sorted requests) forced for
+                       every batch; test batches are small, so the one-wave-per-ray tail does most of it
+      guided_wave_tail0  the same with the tail kernel disabled: every value goes through step/sort/eval"""
     import os
+    os.environ.pop("GPIS_MARCH", None)
+    os.environ.pop("GPIS_WAVE_TAIL", None)
+    if path.startswith("guided_wave"):
+        os.environ["GPIS_MARCH"] = "wave"          # read at every call: stays set until the next _medium()
+        if path.endswith("tail0"):
+            os.environ["GPIS_WAVE_TAIL"] = "0"
     env = {"generic": {"GPIS_DISABLE_FAST": "1"}, "fast_gen": {"GPIS_DISABLE_TABLE": "1"},
            "fast_small_table": {"GPIS_TABLE_HALF_EXTENT": "4"}, "fast": {}}.get(path, {})
     keys = ("GPIS_DISABLE_FAST", "GPIS_DISABLE_TABLE", "GPIS_TABLE_HALF_EXTENT")
@@ -113,7 +122,7 @@ def _medium(pkg, params, path):
         for k in keys:
             os.environ.pop(k, None)
     assert int(med.derived()["fast_path"]) == (0 if path == "generic" else 1)
-    if path == "guided_coarse":
+    if path == "guided_coarse" or path.startswith("guided_wave"):
         med.build_guide(16, 8)
     elif path == "guided_fine_partial":
         med.build_guide(6, 32)
