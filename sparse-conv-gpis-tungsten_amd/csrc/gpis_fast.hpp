@@ -381,8 +381,6 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
 // which is the reference's order (SCN.cpp:383-392), and cells in dx,dy,dz order (SCN.cpp:368-371).
 // ~2.4k instructions per query against ~10k for a cooperative evaluation: used when only a few lanes
 // of a wave need an exact value.  The result is wave-uniform.
-// (Packing two cells per pass at rho <= 32 halves the passes but its extra live values cost the guided
-// kernels 32 B/lane of scratch and 5 % of their time: measured and not done.)
 GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds &lds, int src, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
 {
     const int lane = (int)(threadIdx.x & 63);
@@ -436,6 +434,74 @@ GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds
     return sum;
 }
 
+// The same evaluation with 64 / S cells per pass (two at rho <= 32): lane = (cell of the pass, impulse).
+// Lanes are ordered (cell, k), so walking the ballot upwards visits the impulses in the reference's
+// order, and each cell keeps its own partial sum (cell3D starts from 0, SCN.cpp:380).  Used by the
+// wavefront kernels (gpis_wave.hpp), which have no march state to keep live; in the resident kernels its
+// extra live values cost more in scratch traffic than the halved pass count returns.
+GPIS_DEV float solo_noise3d_value_packed(const DevModel &M, const FastTable &T, FastLds &lds, int src, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const V3 pg = p / R;
+    const V3 fl = v3(floorf(pg.x), floorf(pg.y), floorf(pg.z));
+    const V3 fr = pg - fl;
+    const float fx = lane_f(fr.x, src), fy = lane_f(fr.y, src), fz = lane_f(fr.z, src);
+    const float qx = lane_f(fl.x, src), qy = lane_f(fl.y, src), qz = lane_f(fl.z, src);
+    if (!(fabsf(qx) < 1.0e6f && fabsf(qy) < 1.0e6f && fabsf(qz) < 1.0e6f)) {
+        float r = 0.f;
+        if (lane == src)
+            r = noise3d_per_lane(M, p, seed, R, A0, A1, A2).v;
+        return lane_f(r, src);
+    }
+    const int ci0 = (int)qx, cj0 = (int)qy, ck0 = (int)qz;
+    const uint32_t n = M.n_impulses;
+    const int H = T.half;
+    const int S = n <= 32u ? 32 : 64;      // the table's slots per cell (fast_table_build); also the lane layout without a table
+    const unsigned side = 2u * (unsigned)H;
+    const int per_pass = 64 / S;
+    const int sub = lane / S, k_imp = lane & (S - 1);
+    const unsigned long long cell_bits = S == 64 ? ~0ULL : ((1ULL << S) - 1ULL);
+    float sum = 0.f;
+    for (int c0 = 0; c0 < 27; c0 += per_pass) {
+        const int c = c0 + sub;
+        const int di = c / 9 - 1, dj = (c / 3) % 3 - 1, dk = c % 3 - 1;      // dx, dy, dz order (SCN.cpp:368-371)
+        const int ci = ci0 + di, cj = cj0 + dj, ck = ck0 + dk;
+        float px = 0.f, py = 0.f, pz = 0.f, pw = 0.f;
+        const bool mine = c < 27 && (uint32_t)k_imp < n;
+        if (mine) {
+            if (T.cells && (unsigned)(ci + H) < side && (unsigned)(cj + H) < side && (unsigned)(ck + H) < side) {
+                const size_t idx = (((size_t)(ci + H) * side + (size_t)(cj + H)) * side + (size_t)(ck + H)) * (size_t)S;
+                const float4 v = T.cells[idx + (size_t)k_imp];
+                px = v.x; py = v.y; pz = v.z; pw = v.w;
+            } else {
+                gen_impulse((uint32_t)ci, (uint32_t)cj, (uint32_t)ck, seed, kJump4.A[k_imp], kJump4.C[k_imp], px, py, pz, pw);
+            }
+        }
+        const V3 pc = v3(fx, fy, fz) - v3((float)di, (float)dj, (float)dk);
+        const bool pass = mine && length_sq(pc - v3(px, py, pz)) < 1.0f;
+        const unsigned long long m = __ballot(pass);
+        if (m == 0ULL)
+            continue;
+        const V3 ab = R * pc - R * v3(px, py, pz);
+        const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
+        const float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
+        const float cv = pw * expf_glibc_lds(lds, -absq);
+        for (int g = 0; g < per_pass; ++g) {
+            unsigned long long mg = (m >> (g * S)) & cell_bits;
+            if (mg == 0ULL)
+                continue;                      // an empty cell adds +0: exact to skip
+            float cell = 0.f;
+            while (mg) {
+                const int k = __builtin_ctzll(mg);
+                mg &= mg - 1ULL;
+                cell = cell + lane_f(cv, k + g * S);
+            }
+            sum = sum + cell;
+        }
+    }
+    return sum;
+}
+
 // evaluateNoise3D for the stationary single-realization case (SCN.cpp:101-116, 251-260, 291-320):
 // per-lane transforms exactly as the generic path, the noise3D sum cooperatively.
 // `coord` is the ray's isotropic-ray frame (SCN.cpp:296-297), constant along the segment and hoisted
@@ -474,16 +540,19 @@ GPIS_DEV float coop_evaluate_value(const DevModel &M, const FastTable &T, FastLd
 }
 // evaluateValue (SCN.cpp:73-89) for the single lane `src` through solo_noise3d_value; the value is
 // delivered in lane src's return value (other lanes get an unspecified number).
+template <bool PACKED = false>
 GPIS_DEV float solo_evaluate_value(const DevModel &M, const FastTable &T, FastLds &lds, int src, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
 {
     const int lane = (int)(threadIdx.x & 63);
     float nv;
     if (!M.iso3d) {
         float A0 = M.invcov_world[0] / 1.f / 1.f * 0.5f, A1 = M.invcov_world[4] / 1.f / 1.f * 0.5f, A2 = M.invcov_world[8] / 1.f / 1.f * 0.5f;
-        nv = solo_noise3d_value(M, T, lds, src, p, M.seed, M.radius_world, A0, A1, A2) / M.norm3d_world;
+        nv = (PACKED ? solo_noise3d_value_packed(M, T, lds, src, p, M.seed, M.radius_world, A0, A1, A2)
+                     : solo_noise3d_value(M, T, lds, src, p, M.seed, M.radius_world, A0, A1, A2)) / M.norm3d_world;
     } else {
         V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
-        nv = solo_noise3d_value(M, T, lds, src, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f) / M.norm3d_iso;
+        nv = (PACKED ? solo_noise3d_value_packed(M, T, lds, src, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f)
+                     : solo_noise3d_value(M, T, lds, src, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f)) / M.norm3d_iso;
     }
     if (lane == src) n_eval++;
     double mean;

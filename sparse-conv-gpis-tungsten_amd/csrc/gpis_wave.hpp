@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(kFastBlock) k_wave_tail(const DevModel *__rest
             break;
         const V3 pq = wave_point(w, wave_request_t(w, s));
         int gp;
-        const float fv = solo_evaluate_value(M, T, lds, 0, pq, coord, gp, n_eval);
+        const float fv = solo_evaluate_value<true>(M, T, lds, 0, pq, coord, gp, n_eval);
         const float fv0 = lane_f(fv, 0);
         wave_consume<WANT_SAMPLE>(w, s, fv0, __builtin_amdgcn_readfirstlane(gp));
     }
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_wave_eval(const D
             for (unsigned long long mm = cl_mask; mm; mm &= mm - 1ULL) {
                 const int src = __builtin_ctzll(mm);
                 int gpx;
-                const float v = solo_evaluate_value(M, T, lds, src, pq, coord, gpx, n_eval);
+                const float v = solo_evaluate_value<true>(M, T, lds, src, pq, coord, gpx, n_eval);
                 if ((int)(threadIdx.x & 63) == src) { fv = v; gp = gpx; }
             }
         } else {
