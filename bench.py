@@ -37,6 +37,19 @@ def algorithmic_bytes_per_eval(params):
     return (3 * rho * 8 * L) if params["sampling_1d"] else (27 * rho * 16 * L)
 
 
+def algorithmic_ops_per_eval(params):
+    """SURVEY.md §8d, secondary figure for the VALU roof: 27*[H + (2+4*rho)*P + rho*D] + 0.155*27*rho*K
+    with H=24 (hash), P=14 (PCG draw), D=10 (distance test), K=40 (kernel); 3 cells and 2 draws per impulse in 1D."""
+    rho = int(params["impulse_density"])
+    L = 2 if (params["nonstationary"] and params["multi_resolution_grid"]) else 1
+    if params["sampling_1d"]:
+        return L * (3 * (24 + (2 + 2 * rho) * 14 + rho * 6) + 3 * rho * 40)
+    return L * (27 * (24 + (2 + 4 * rho) * 14 + rho * 10) + 0.155 * 27 * rho * 40)
+
+
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12      # one simple VALU op per lane and clock: 39.3 Tops/s (MI355X_MICROARCH.md: 157.3 TF = x2 packed x2 FMA)
+
+
 def load_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -209,6 +222,10 @@ def main():
                 "bytes_per_eval": b_eval, "bytes_per_segment": B_SEG, "n_eval": n_eval, "n_seg": n_seg,
                 "evals_per_s": (prof[0][2] + prof[1][2]) / dt_max,
                 "certified_steps": n_guide, "certified_steps_per_s": n_guide / dt_max,
+                "valu": {"doc": "secondary roof (SURVEY.md 8d): algorithmic VALU ops of the exact evaluations the dominant kernel performed / its time; "
+                                "exceeds the peak because one generated or gathered impulse serves the 64 queries of a wave",
+                         "ops_per_eval": algorithmic_ops_per_eval(params), "achieved_Tops": n_eval * algorithmic_ops_per_eval(params) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                         "peak_Tops": VALU_PEAK_TOPS},
                 "reference_equivalent": {"evals": n_eval_all, "segments": n_seg_all, "GBps": ref_equiv,
                                          "doc": "both medium kernels, counting a certified march step as the evaluation it replaces"},
                 "kernel_ms": {names[0]: prof[0][0], names[1]: prof[1][0]},
