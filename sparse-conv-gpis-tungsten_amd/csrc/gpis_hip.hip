@@ -1591,6 +1591,29 @@ extern "C" void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t h
     s->y_begin = 0; s->y_count = height;
 }
 
+// Samples per chunk of the tile drivers: 2^default_log2 unless GPIS_CHUNK_LOG2 says otherwise.  Chunks are
+// sized for the 288 GB of an MI355X — one launch per stage and frame where it fits — because every launch
+// ends in a tail of half-empty waves and the wavefront march in a tail of thin iterations (C1 frame:
+// 8 Mi-sample chunks 268.8, 32 Mi 284.8, 128 Mi 291.3 Msamples/s; multi-bounce 65 → 80 M paths/s).
+static int chunk_log2(int default_log2)
+{
+    int l = default_log2;
+    if (const char *e = getenv("GPIS_CHUNK_LOG2")) l = atoi(e);
+    if (l < 16) l = 16;
+    if (l > 28) l = 28;
+    return l;
+}
+// grows stage[slot] to `bytes` if the device has the memory; false (and no error state) otherwise
+static bool try_stage(gpis_medium *m, int slot, size_t bytes)
+{
+    if (m->stage_bytes[slot] >= bytes)
+        return true;
+    if (ensure_stage(m, slot, bytes) == GPIS_OK)
+        return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 static SceneConst make_scene_const(const gpis_scene_s *s)
 {
     SceneConst sc;
@@ -1619,18 +1642,24 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = (size_t)s->y_count * s->width;
     const size_t first_pixel0 = (size_t)s->y_begin * s->width;
-    const size_t target_samples = (size_t)1 << 23;   // ~8 Mi samples (≈3 GB of workspace) per chunk
-    size_t chunk_pixels = target_samples / s->spp_count;
-    if (chunk_pixels < 1) chunk_pixels = 1;
-    if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
-    const size_t ns_max = chunk_pixels * s->spp_count;
-    // workspace: [prim rays | seg out | shadow rays | u_shadow | cosl | valid | valid2 | vis | hit]
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t o_prim = carve(ns_max * sizeof(gpis_ray_in)), o_seg = carve(ns_max * sizeof(gpis_seg_out)), o_sh = carve(ns_max * sizeof(gpis_ray_in));
-    size_t o_us = carve(ns_max * 4), o_cos = carve(ns_max * 4), o_v1 = carve(ns_max), o_v2 = carve(ns_max), o_vis = carve(ns_max), o_hit = carve(ns_max);
-    int rc = ensure_stage(m, 3, off);
-    if (rc) return rc;
+    // workspace: [prim rays | seg out | shadow rays | u_shadow | cosl | valid | valid2 | vis | hit], ≈375 B per sample;
+    // the largest chunk the device can hold, starting from the whole frame (2^27 samples ≈ 50 GB)
+    size_t chunk_pixels = 0, ns_max = 0, off = 0;
+    size_t o_prim = 0, o_seg = 0, o_sh = 0, o_us = 0, o_cos = 0, o_v1 = 0, o_v2 = 0, o_vis = 0, o_hit = 0;
+    int rc = GPIS_OK;
+    for (int l = chunk_log2(27);; --l) {
+        chunk_pixels = ((size_t)1 << l) / s->spp_count;
+        if (chunk_pixels < 1) chunk_pixels = 1;
+        if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
+        ns_max = chunk_pixels * s->spp_count;
+        off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        o_prim = carve(ns_max * sizeof(gpis_ray_in)); o_seg = carve(ns_max * sizeof(gpis_seg_out)); o_sh = carve(ns_max * sizeof(gpis_ray_in));
+        o_us = carve(ns_max * 4); o_cos = carve(ns_max * 4); o_v1 = carve(ns_max); o_v2 = carve(ns_max); o_vis = carve(ns_max); o_hit = carve(ns_max);
+        if (try_stage(m, 3, off))
+            break;
+        if (l <= 20) return set_err(GPIS_ERR_DEVICE, "scene driver: no memory for a 1 Mi-sample workspace");
+    }
     char *ws = (char *)m->stage[3];
     gpis_ray_in *prim = (gpis_ray_in *)(ws + o_prim);
     gpis_seg_out *seg = (gpis_seg_out *)(ws + o_seg);
@@ -1662,7 +1691,7 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = (size_t)s->y_count * s->width;
     const size_t first_pixel0 = (size_t)s->y_begin * s->width;
-    size_t chunk_pixels = ((size_t)1 << 23) / s->spp_count;
+    size_t chunk_pixels = ((size_t)1 << chunk_log2(25)) / s->spp_count;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
     const size_t ns_max = chunk_pixels * s->spp_count;
@@ -1762,7 +1791,7 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = (size_t)s->y_count * s->width;
     const size_t first_pixel0 = (size_t)s->y_begin * s->width;
-    size_t chunk_pixels = ((size_t)1 << 22) / s->spp_count;
+    size_t chunk_pixels = ((size_t)1 << chunk_log2(24)) / s->spp_count;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
     const size_t ns_max = chunk_pixels * s->spp_count;
