@@ -166,6 +166,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step()      # set-up, like the guide build: the first render allocates the driver's workspace (50 GB for a C1 frame)
     for _ in range(args.warmup):
         step()
     fence()
