@@ -306,6 +306,14 @@ int gpis_reset_counters(gpis_medium *m);
  * number of launches, and that kernel's share of the evaluation / segment counters since the
  * last gpis_reset_counters.  Synchronises the device. */
 int gpis_set_profiling(gpis_medium *m, int enable);
+
+/* How the rays of the *_batch / *_host march entries are ordered.  Results never depend on it; with a
+ * guide field built it selects the form of the march: GPIS_ORDER_COHERENT (default) — the 64 consecutive
+ * records of a wave are neighbours in lattice space (camera rays in pixel order): one resident kernel per
+ * batch; GPIS_ORDER_SCATTERED — arbitrary order (bounced rays of a wavefront integrator): the march
+ * runs as step / sort / evaluate iterations that regroup the exact evaluations by lattice cell. */
+enum { GPIS_ORDER_COHERENT = 0, GPIS_ORDER_SCATTERED = 1 };
+int gpis_set_batch_order(gpis_medium *m, int order);
 int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_t *launches,
                             uint64_t *n_eval, uint64_t *n_seg);
 

@@ -210,7 +210,7 @@ class GpisLib:
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
-        "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
+        "gpis_set_batch_order", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
         "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
     ]
 
@@ -405,6 +405,9 @@ class Medium:
         self.L.check(self.L.lib.gpis_guide_raycheck(self.h, int(n), ctypes.c_void_p(int(rays_dev_ptr)), int(steps), ctypes.byref(c),
                                                     ctypes.byref(v), stream), "gpis_guide_raycheck")
         return c.value, v.value
+
+    def set_batch_order(self, scattered):
+        self.L.check(self.L.lib.gpis_set_batch_order(self.h, 1 if scattered else 0), "gpis_set_batch_order")
 
     def set_profiling(self, on):
         self.L.check(self.L.lib.gpis_set_profiling(self.h, int(bool(on))), "gpis_set_profiling")

@@ -76,6 +76,7 @@ struct gpis_medium {
     size_t stage_bytes[5];
     std::mutex mu;
     // optional per-kernel timing (gpis_set_profiling): event pairs around each march launch
+    int batch_hint;          // gpis_set_batch_order: which form of the guided march the *_batch / *_host entries use
     bool profiling;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];
     size_t events_used[2];
@@ -1005,6 +1006,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     m->device = device;
     for (int i = 0; i < 5; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
     m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr;
+    m->batch_hint = GPIS_ORDER_COHERENT;
     memset(&m->guide, 0, sizeof m->guide);
     m->profiling = false;
     for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
@@ -1100,7 +1102,7 @@ struct ProfScope {   // records an event pair around one march-kernel launch whe
 // Which form runs: the resident kernels win on batches whose waves are already coherent (camera rays in
 // pixel order: 131 vs 181 ms on C1), the wavefront on scattered rays (1.4x on the second bounce), so the
 // caller's hint decides; GPIS_MARCH=wave|resident overrides it.
-enum MarchHint { MARCH_COHERENT = 0, MARCH_SCATTERED = 1 };
+enum MarchHint { MARCH_COHERENT = GPIS_ORDER_COHERENT, MARCH_SCATTERED = GPIS_ORDER_SCATTERED };
 static bool wave_march_selected(int hint)
 {
     const char *e = getenv("GPIS_MARCH");
@@ -1249,13 +1251,19 @@ extern "C" int gpis_sample_distance_batch(gpis_medium *m, size_t n, const gpis_r
 {
     CHECK_ARGS(m && (n == 0 || (rays && out)));
     HIP_TRY(hipSetDevice(m->device));
-    return sample_distance_impl(m, n, rays, out, coeff, nullptr, (hipStream_t)stream);
+    return sample_distance_impl(m, n, rays, out, coeff, nullptr, (hipStream_t)stream, m->batch_hint);
 }
 extern "C" int gpis_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && visible)));
     HIP_TRY(hipSetDevice(m->device));
-    return transmittance_impl(m, n, rays, visible, nullptr, (hipStream_t)stream);
+    return transmittance_impl(m, n, rays, visible, nullptr, (hipStream_t)stream, m->batch_hint);
+}
+extern "C" int gpis_set_batch_order(gpis_medium *m, int order)
+{
+    CHECK_ARGS(m && (order == GPIS_ORDER_COHERENT || order == GPIS_ORDER_SCATTERED));
+    m->batch_hint = order;
+    return GPIS_OK;
 }
 extern "C" int gpis_eval_value_batch(gpis_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id, void *stream)
 {

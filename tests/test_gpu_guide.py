@@ -89,6 +89,15 @@ def test_guided_march_matches_oracle_and_saves_evaluations(pkg, ob):
     # every evaluation of the exact march is either certified or performed; the only extra work is the
     # one re-evaluation of a certified previous step when a crossing is refined (at most one per segment)
     assert 0 <= e_guided + n_guide - e_exact <= len(rays)
+    # the same rays in a random order through the entry for scattered batches (wavefront form of the march)
+    perm = np.random.default_rng(3).permutation(len(rays))
+    med.set_batch_order(True)
+    shuffled = med.sample_distance(rays[perm])
+    for f in shuffled.dtype.names:
+        assert np.array_equal(shuffled[f], want[f][perm], equal_nan=True), f
+    assert np.array_equal(med.transmittance(sh), vis_o)
+    med.set_batch_order(False)
+    assert med.L.lib.gpis_set_batch_order(med.h, 7) == -1
     med.drop_guide()
     again = med.sample_distance(rays)
     assert np.array_equal(again["t"], want["t"])
