@@ -540,6 +540,40 @@ def test_render_scene_s_nee(env, scheme):
     assert med.L.lib.gpis_render_scene_s_nee(med.h, sc.ctypes.data_as(ctypes.c_void_p), bad.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None) == -1
 
 
+def test_drivers_on_other_media(env):
+    """The whole-estimator drivers on the media the fixed cases above do not combine them with: the
+    multi-bounce driver on per-path realizations with live Renewal conditioning (lane-per-ray kernels, state
+    carried from bounce to bounce), and the NEE driver on a single-realization medium, where neePDF is disabled
+    (SCN.cpp:23-26: the scheme degenerates to UNI) and the segments run on the guided kernels."""
+    import torch
+    pkg, ob, lib = env
+    w, h, spp = 48, 48, 4
+    scene = ob.default_scene_s(w, h, spp)
+    sc = np.array(scene, dtype=pkg.SCENE_S)
+    rad = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+    # multi-bounce, per-path realizations
+    params = pkg.params_for_config("C0")
+    params["single_realization"] = 0
+    params["correlation_context"] = pkg.CTX.RENEWAL
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    want = orc.render_scene_s_paths(scene, 3, 0.7)
+    med.call("gpis_render_scene_s_paths", sc.ctypes.data_as(ctypes.c_void_p), 3, 0.7, rad.data_ptr(), stream_ptr())
+    torch.cuda.synchronize()
+    assert want.sum() > 0 and np.array_equal(rad.cpu().numpy().reshape(h, w), want)
+    # NEE driver, single realization (guided kernels, UNI scheme): a wide cap so that mirror directions hit it
+    params = pkg.params_for_config("C1")
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    med.build_guide(16, 8)
+    surf = pkg.default_surface_s()
+    surf["cap_cos"] = 0.5
+    want = orc.render_scene_s_nee(scene, surf)
+    sf = np.array(surf, dtype=pkg.SURFACE_S)
+    rad.zero_()
+    med.call("gpis_render_scene_s_nee", sc.ctypes.data_as(ctypes.c_void_p), sf.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), stream_ptr())
+    torch.cuda.synchronize()
+    assert want.sum() > 0 and np.array_equal(rad.cpu().numpy().reshape(h, w), want)
+
+
 def test_error_behaviour(env):
     pkg, ob, lib = env
     bad = pkg.params_for_config("C0")
