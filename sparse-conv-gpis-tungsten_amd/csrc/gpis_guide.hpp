@@ -52,6 +52,11 @@ struct GuideField {
 // occ3 149, occ4 137, occ5 146, occ6 154, occ8 183
 #define GPIS_GUIDE_OCC 4
 #endif
+#ifndef GPIS_GUIDE_OCC_TR
+// transmittance carries less state (no lastVal / gradient tail): whole C1 frames, sd / tr ms at 3 waves 336 / 135,
+// 4 waves 315 / 122, 5 waves 325 / 117
+#define GPIS_GUIDE_OCC_TR 5
+#endif
 #ifndef GPIS_SOLO_MAX
 #define GPIS_SOLO_MAX 3
 #endif
@@ -580,7 +585,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_di
     if ((threadIdx.x & 63) == 0 && gsum) atomicAdd(guide_cnt, gsum);
 }
 
-__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC_TR) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
                                                                                    const gpis_ray_in *__restrict__ rays, uint8_t *__restrict__ visible,
                                                                                    const uint8_t *__restrict__ mask, Counters *cnt, unsigned long long *guide_cnt)
 {

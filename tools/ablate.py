@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     import _gpis_pkg, torch
     pkg = _gpis_pkg.load_package()
     lib = pkg.GpisLib(sys.argv[2])
-    w, h, spp = 960, 540, 64
+    w, h, spp = (int(x) for x in os.environ.get("ABLATE_RES", "960x540x64").split("x"))
     med = pkg.Medium(pkg.params_for_config("C1"), lib=lib)
     if os.environ.get("ABLATE_GUIDE", "16:32") != "off":
         gh, gp = (int(x) for x in os.environ.get("ABLATE_GUIDE", "16:32").split(":"))
