@@ -3,6 +3,8 @@ seeded random parameter blocks (kernel anisotropy, means incl. linear and CSG-mi
 spaces, contexts, densities, step sizes, non-stationary ramps) go through both implementations.
 Expectation per case: the 3D stationary chain is bit-exact; anything that passes through double
 libm (1D gradient, length-scale ramps: DESIGN.md §2) is compared with a tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -84,7 +86,7 @@ def _random_rays(ob, rng, n):
     return r
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPIS_FUZZ_FIRST", "0")), int(os.environ.get("GPIS_FUZZ_FIRST", "0")) + int(os.environ.get("GPIS_FUZZ_SEEDS", "32"))))
 def test_random_configuration(pkg, ob, seed):
     rng = np.random.default_rng(1000 + seed)
     params = _random_params(pkg, rng)
