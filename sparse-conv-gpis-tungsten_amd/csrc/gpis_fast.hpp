@@ -158,8 +158,15 @@ constexpr int kFastBlock = 64;          // one wave per workgroup
 #ifndef GPIS_FAST_OCC
 #define GPIS_FAST_OCC 3                 // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef GPIS_LDS_BCAST
+#define GPIS_LDS_BCAST 1                // 1: candidate impulses are broadcast through LDS, 0: with v_readlane
+#endif
 struct FastLds {
     uint64_t exptab[32];                // glibc's exp2f table, staged once per wave (ds_read_b64 per use)
+#if GPIS_LDS_BCAST
+    float4 imp[64];                     // the current cell's impulses (x, y, z, w) ...
+    float4 rimp[64];                    // ... and kernelRadius * (x, y, z): read back at a wave-uniform address
+#endif
 };
 GPIS_DEV void fast_lds_init(FastLds &lds)
 {
@@ -334,9 +341,22 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
         // test fails for them and their cell sum stays +0
         const V3 pc = mine ? frac - v3((float)di, (float)dj, (float)dk) : v3(8.f, 8.f, 8.f);
         const V3 Rp = R * pc;
+#if GPIS_LDS_BCAST
+        // The kernel is VALU-issue bound and the 7 v_readlane per candidate are VALU instructions; an LDS
+        // read at a wave-uniform address is a broadcast that issues on the LDS pipe instead.  One wave per
+        // workgroup, LDS operations of a wave execute in order: no barrier between the stores and the loads.
+        lds.imp[lane] = make_float4(px, py, pz, pw);
+        lds.rimp[lane] = make_float4(rx, ry, rz, 0.f);
+#endif
         auto contribution = [&](int k) {
+#if GPIS_LDS_BCAST
+            const float4 iv = lds.imp[k], jv = lds.rimp[k];
+            const float ix = iv.x, iy = iv.y, iz = iv.z, iw = iv.w;
+            const float jx = jv.x, jy = jv.y, jz = jv.z;
+#else
             const float ix = lane_f(px, k), iy = lane_f(py, k), iz = lane_f(pz, k), iw = lane_f(pw, k);
             const float jx = lane_f(rx, k), jy = lane_f(ry, k), jz = lane_f(rz, k);
+#endif
             const bool pass = length_sq(pc - v3(ix, iy, iz)) < 1.0f;
             const V3 ab = Rp - v3(jx, jy, jz);
             const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
