@@ -158,14 +158,17 @@ constexpr int kFastBlock = 64;          // one wave per workgroup
 #ifndef GPIS_FAST_OCC
 #define GPIS_FAST_OCC 3                 // waves per SIMD the register allocator must leave room for
 #endif
+typedef float float2v __attribute__((ext_vector_type(2)));    // two fp32 lanes of a v_pk_* instruction
 #ifndef GPIS_LDS_BCAST
 #define GPIS_LDS_BCAST 1                // 1: candidate impulses are broadcast through LDS, 0: with v_readlane
 #endif
 struct FastLds {
     uint64_t exptab[32];                // glibc's exp2f table, staged once per wave (ds_read_b64 per use)
 #if GPIS_LDS_BCAST
-    float4 imp[64];                     // the current cell's impulses (x, y, z, w) ...
-    float4 rimp[64];                    // ... and kernelRadius * (x, y, z): read back at a wave-uniform address
+    // the current cell's impulses, read back at a wave-uniform address (= broadcast), laid out in the
+    // pairs the candidate body consumes with packed fp32 instructions
+    float4 xyr[64];                     // (x, y, kernelRadius * x, kernelRadius * y)
+    float4 zw[64];                      // (z, kernelRadius * z, w = +-1, unused)
 #endif
 };
 GPIS_DEV void fast_lds_init(FastLds &lds)
@@ -182,7 +185,9 @@ GPIS_DEV float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirst
 // lane k's value, k wave-uniform (v_readlane_b32: no LDS round trip)
 GPIS_DEV float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
-// expf_glibc with the table in LDS and the range checks folded into selects (same results)
+// expf_glibc with the table in LDS and the range checks folded into selects (same results).
+// NONPOS: the caller guarantees x <= 0 (or NaN), so the overflow check cannot fire and is left out.
+template <bool NONPOS = false>
 GPIS_DEV float expf_glibc_lds(const FastLds &lds, float x)
 {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32;
@@ -204,7 +209,8 @@ GPIS_DEV float expf_glibc_lds(const FastLds &lds, float x)
     y = y * __longlong_as_double((long long)t);
     float res = (float)y;
     res = x < -0x1.9fe368p6f ? 0.0f : res;
-    res = x > 0x1.62e42ep6f ? __builtin_huge_valf() : res;
+    if (!NONPOS)
+        res = x > 0x1.62e42ep6f ? __builtin_huge_valf() : res;
     return res;
 }
 
@@ -345,18 +351,42 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
         // The kernel is VALU-issue bound and the 7 v_readlane per candidate are VALU instructions; an LDS
         // read at a wave-uniform address is a broadcast that issues on the LDS pipe instead.  One wave per
         // workgroup, LDS operations of a wave execute in order: no barrier between the stores and the loads.
-        lds.imp[lane] = make_float4(px, py, pz, pw);
-        lds.rimp[lane] = make_float4(rx, ry, rz, 0.f);
-#endif
+        lds.xyr[lane] = make_float4(px, py, rx, ry);
+        lds.zw[lane] = make_float4(pz, rz, pw, 0.f);
+        // the body in packed fp32 pairs; every element is the reference's own operation:
+        //   lengthSq(pc - p_i) = (dx^2 + dy^2) + dz^2          (Vec.hpp:200-206)
+        //   ab^T A ab          = tx*abx + (ty*aby + tz*abz)    (Eigen 3-term reduction), t = ab * diag(A)
+        const float2v pcxy = float2v{pc.x, pc.y}, Rpxy = float2v{Rp.x, Rp.y}, pzRz = float2v{pc.z, Rp.z}, Axy = float2v{A0, A1};
         auto contribution = [&](int k) {
-#if GPIS_LDS_BCAST
-            const float4 iv = lds.imp[k], jv = lds.rimp[k];
-            const float ix = iv.x, iy = iv.y, iz = iv.z, iw = iv.w;
-            const float jx = jv.x, jy = jv.y, jz = jv.z;
+            const float4 qa = lds.xyr[k], qb = lds.zw[k];
+            const float2v ixy = float2v{qa.x, qa.y}, rxy = float2v{qa.z, qa.w}, zrz = float2v{qb.x, qb.y};
+            const float iw = qb.z;
+            const float2v dxy = pcxy - ixy;             // (pc.x - x, pc.y - y)
+            const float2v abxy = Rpxy - rxy;            // (ab.x, ab.y)
+            const float2v dzab = pzRz - zrz;            // (pc.z - z, ab.z)
+            const float2v d2 = dxy * dxy;
+            const float2v txy = abxy * Axy;             // (t.x, t.y)
+            const float2v tab = txy * abxy;
+            const float tz = dzab.y * A2;
+            const float2v zz = float2v{dzab.x, tz} * dzab;     // (dz^2, t.z * ab.z)
+            const bool pass = ((d2.x + d2.y) + zz.x) < 1.0f;
+            const float absq = tab.x + (tab.y + zz.y);
+            const float f = expf_glibc_lds<true>(lds, -absq);
+            V4 r;
+            r.v = pass ? iw * f : 0.f;
+            if (GRAD) {
+                r.gx = pass ? iw * (-2.f * txy.x * f) : 0.f;
+                r.gy = pass ? iw * (-2.f * txy.y * f) : 0.f;
+                r.gz = pass ? iw * (-2.f * tz * f) : 0.f;
+            } else {
+                r.gx = r.gy = r.gz = 0.f;
+            }
+            return r;
+        };
 #else
+        auto contribution = [&](int k) {
             const float ix = lane_f(px, k), iy = lane_f(py, k), iz = lane_f(pz, k), iw = lane_f(pw, k);
             const float jx = lane_f(rx, k), jy = lane_f(ry, k), jz = lane_f(rz, k);
-#endif
             const bool pass = length_sq(pc - v3(ix, iy, iz)) < 1.0f;
             const V3 ab = Rp - v3(jx, jy, jz);
             const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
@@ -373,6 +403,7 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
             }
             return r;
         };
+#endif
         V4 cell = v4(0.f, 0.f, 0.f, 0.f);
         while (cand) {
             const int k0 = __builtin_ctzll(cand);
