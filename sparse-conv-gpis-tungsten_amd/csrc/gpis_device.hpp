@@ -51,6 +51,7 @@ struct DevModel {
     // stationary fast constants (valid when !nonstationary)
     float radius_world, radius_iso;       // splattingKernelRadius(false/true, 1)
     float norm3d_world, norm3d_iso, norm1d;   // sqrt(variance) (SCN.cpp:254, 279, 308, 331)
+    float exp_arg_max;                        // max_a(A_a) * R^2 of the grid space in use: bound on ab^T A ab inside the unit ball
     // non-stationary ramp (GPF.cpp:87-95, GPF.hpp:773-774)
     int32_t ls_ramp_type;
     float ls_maxval;

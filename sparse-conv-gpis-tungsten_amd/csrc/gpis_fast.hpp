@@ -187,7 +187,9 @@ GPIS_DEV float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_r
 
 // expf_glibc with the table in LDS and the range checks folded into selects (same results).
 // NONPOS: the caller guarantees x <= 0 (or NaN), so the overflow check cannot fire and is left out.
-template <bool NONPOS = false>
+// NOUNDER: the caller guarantees that every result it USES has x >= -100 (results of smaller x are
+// discarded), so the underflow select is left out as well.
+template <bool NONPOS = false, bool NOUNDER = false>
 GPIS_DEV float expf_glibc_lds(const FastLds &lds, float x)
 {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32;
@@ -208,7 +210,8 @@ GPIS_DEV float expf_glibc_lds(const FastLds &lds, float x)
     y = __builtin_fma(zz, r2, y);
     y = y * __longlong_as_double((long long)t);
     float res = (float)y;
-    res = x < -0x1.9fe368p6f ? 0.0f : res;
+    if (!NOUNDER)
+        res = x < -0x1.9fe368p6f ? 0.0f : res;
     if (!NONPOS)
         res = x > 0x1.62e42ep6f ? __builtin_huge_valf() : res;
     return res;
@@ -225,7 +228,10 @@ GPIS_DEV V4 noise3d_per_lane(const DevModel &M, V3 p, uint32_t seed, float R, fl
 //   p      : the lane's query point in the space the grid lives in (world, or isotropic-ray space)
 //   R      : kernelRadius (wave-uniform);  A0..A2: diagonal of getInvCovMtx (wave-uniform)
 // Returns (value, gradient) — gradient only when GRAD.
-template <bool GRAD>
+// SMALLARG: max_a(A_a) * R^2 < 100 for this medium (DevModel::exp_arg_max, checked by the launcher): a lane
+// that passes the unit-ball test has ab^T A ab < 100, far from expf's underflow threshold (103.97), and the
+// value computed for a failing lane is discarded — the underflow select of expf is dead code there.
+template <bool GRAD, bool SMALLARG = false>
 GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
 {
     const int lane = (int)(threadIdx.x & 63);
@@ -371,7 +377,7 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
             const float2v zz = float2v{dzab.x, tz} * dzab;     // (dz^2, t.z * ab.z)
             const bool pass = ((d2.x + d2.y) + zz.x) < 1.0f;
             const float absq = tab.x + (tab.y + zz.y);
-            const float f = expf_glibc_lds<true>(lds, -absq);
+            const float f = expf_glibc_lds<true, SMALLARG>(lds, -absq);
             V4 r;
             r.v = pass ? iw * f : 0.f;
             if (GRAD) {
@@ -557,7 +563,7 @@ GPIS_DEV float solo_noise3d_value_packed(const DevModel &M, const FastTable &T, 
 // per-lane transforms exactly as the generic path, the noise3D sum cooperatively.
 // `coord` is the ray's isotropic-ray frame (SCN.cpp:296-297), constant along the segment and hoisted
 // out of the march by the caller.
-template <bool GRAD>
+template <bool GRAD, bool SMALLARG = false>
 GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
 {
     if (active) n_eval++;
@@ -565,11 +571,11 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &ld
         float R = M.radius_world;
         // getInvCovMtx(isCov=false, isIsotropic=false, globalScale=1, localScale=1): ((A / 1) / 1) * 0.5
         float A0 = M.invcov_world[0] / 1.f / 1.f * 0.5f, A1 = M.invcov_world[4] / 1.f / 1.f * 0.5f, A2 = M.invcov_world[8] / 1.f / 1.f * 0.5f;
-        V4 nz = coop_noise3d<GRAD>(M, T, lds, active, p, M.seed, R, A0, A1, A2);
+        V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p, M.seed, R, A0, A1, A2);
         return nz / M.norm3d_world;
     }
     V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
-    V4 nz = coop_noise3d<GRAD>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f);
+    V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f);
     if (GRAD) {
         V3 gw = cov_grad_l2w(M, to_global(coord, v3(nz.gx, nz.gy, nz.gz)), 1.0f);
         return v4(nz.v, gw.x, gw.y, gw.z) / M.norm3d_iso;
@@ -578,9 +584,10 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &ld
 }
 
 // evaluateValue, SCN.cpp:73-89
+template <bool SMALLARG = false>
 GPIS_DEV float coop_evaluate_value(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
 {
-    float nv = coop_eval_noise3d<false>(M, T, lds, active, p, coord, n_eval).v;
+    float nv = coop_eval_noise3d<false, SMALLARG>(M, T, lds, active, p, coord, n_eval).v;
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);
@@ -615,9 +622,10 @@ GPIS_DEV float solo_evaluate_value(const DevModel &M, const FastTable &T, FastLd
     return (float)((double)(M.sigma * nv) + mean);
 }
 // evaluateGradient, SCN.cpp:92-99
+template <bool SMALLARG = false>
 GPIS_DEV V3 coop_evaluate_gradient(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
 {
-    V4 nz = coop_eval_noise3d<true>(M, T, lds, active, p, coord, n_eval);
+    V4 nz = coop_eval_noise3d<true, SMALLARG>(M, T, lds, active, p, coord, n_eval);
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);

@@ -300,7 +300,7 @@ GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRa
     return 0;
 }
 
-template <bool WANT_SAMPLE>
+template <bool WANT_SAMPLE, bool SMALLARG>
 GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideField &F, FastLds &lds, bool valid,
                            const gpis_ray_in *__restrict__ rayp, gpis_seg_out *out, bool &visible, uint32_t &n_eval, uint32_t &n_guide)
 {
@@ -475,7 +475,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
                 if ((int)(threadIdx.x & 63) == src) { fv = v; gp_new = gpx; }
             }
         } else {
-            fv = coop_evaluate_value(M, T, lds, in_cluster, pq, coord, gp_new, n_eval);
+            fv = coop_evaluate_value<SMALLARG>(M, T, lds, in_cluster, pq, coord, gp_new, n_eval);
         }
 #ifdef GPIS_FAST_STATS
         for (int ph = X_F0; ph <= X_FINAL; ++ph) {
@@ -546,7 +546,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
             const int lead = __builtin_ctzll(pm);
             const int ax0 = __builtin_amdgcn_readlane(cx, lead), ay0 = __builtin_amdgcn_readlane(cy, lead), az0 = __builtin_amdgcn_readlane(cz, lead);
             const bool in_cluster = pending && cx >= ax0 && cx <= ax0 + 1 && cy >= ay0 && cy <= ay0 + 1 && cz >= az0 && cz <= az0 + 1;
-            const V3 gi = coop_evaluate_gradient(M, T, lds, in_cluster, pgq, coord, n_eval);
+            const V3 gi = coop_evaluate_gradient<SMALLARG>(M, T, lds, in_cluster, pgq, coord, n_eval);
             if (in_cluster) {
                 g = gi;
                 pending = false;
@@ -561,6 +561,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
 
 struct GuideCounters { unsigned long long n_guide; };
 
+template <bool SMALLARG>
 __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_distance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
                                                                                      const gpis_ray_in *__restrict__ rays, gpis_seg_out *__restrict__ out,
                                                                                      gpis_cond_coeff *__restrict__ coeff, const uint8_t *__restrict__ mask,
@@ -572,7 +573,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_di
     const bool valid = i < n && (!mask || mask[i]);
     uint32_t n_eval = 0, n_guide = 0;
     bool vis;
-    guided_march<true>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval, n_guide);
+    guided_march<true, SMALLARG>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval, n_guide);
     if (valid && coeff) {
         gpis_cond_coeff c;
         memset(&c, 0, sizeof c);
@@ -585,6 +586,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_di
     if ((threadIdx.x & 63) == 0 && gsum) atomicAdd(guide_cnt, gsum);
 }
 
+template <bool SMALLARG>
 __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC_TR) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
                                                                                    const gpis_ray_in *__restrict__ rays, uint8_t *__restrict__ visible,
                                                                                    const uint8_t *__restrict__ mask, Counters *cnt, unsigned long long *guide_cnt)
@@ -595,7 +597,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC_TR) k_guided_transm
     const bool valid = i < n && (!mask || mask[i]);
     uint32_t n_eval = 0, n_guide = 0;
     bool vis = false;
-    guided_march<false>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), nullptr, vis, n_eval, n_guide);
+    guided_march<false, SMALLARG>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), nullptr, vis, n_eval, n_guide);
     if (i < n)
         visible[i] = (valid && vis) ? 1 : 0;
     fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);

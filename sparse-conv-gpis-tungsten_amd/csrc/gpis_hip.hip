@@ -221,6 +221,12 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
     M.radius_iso = M.kernel_scale;
     M.radius_world = M.kernel_scale * 1.0f * M.mtx_factor;
     M.norm3d_world = sqrtf(variance3d(P.impulse_density, M.radius_world, false, 1.0f, 1.0f));
+    {   // bound on ab^T A ab inside the unit ball, for the grid space the cooperative kernels use (A as in coop_eval_noise3d)
+        const float amax = M.iso3d ? 0.5f : 0.5f * fmaxf(M.invcov_world[0], fmaxf(M.invcov_world[4], M.invcov_world[8]));
+        const float R = M.iso3d ? M.kernel_scale : M.radius_world;
+        const float v = amax * R * R * 1.01f;
+        M.exp_arg_max = (v == v && v >= 0.f) ? v : 3.4e38f;
+    }
     M.norm3d_iso = sqrtf(variance3d(P.impulse_density, M.radius_iso, true, 1.0f, 1.0f));
     {
         double idua = P.impulse_density / M.radius_iso;
@@ -1197,7 +1203,10 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
     if (m->guide.enabled && wave_march_selected(hint))
         return wave_march(m, n, rays, mask, true, out, coeff, nullptr, s);
     if (m->guide.enabled) {
-        k_guided_sample_distance<<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
+        if (m->host_model.exp_arg_max < 100.f)
+            k_guided_sample_distance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
+        else
+            k_guided_sample_distance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
         return launch_check("k_guided_sample_distance");
     }
     if (m->fast.enabled) {
@@ -1226,7 +1235,10 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
     if (m->guide.enabled && wave_march_selected(hint))
         return wave_march(m, n, rays, mask, false, nullptr, nullptr, visible, s);
     if (m->guide.enabled) {
-        k_guided_transmittance<<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
+        if (m->host_model.exp_arg_max < 100.f)
+            k_guided_transmittance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
+        else
+            k_guided_transmittance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
         return launch_check("k_guided_transmittance");
     }
     if (m->fast.enabled) {
