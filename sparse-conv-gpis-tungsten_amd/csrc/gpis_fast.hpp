@@ -479,7 +479,7 @@ GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds
                 const V3 ab = R * pc - R * v3(px, py, pz);
                 const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
                 const float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
-                const float c = pw * expf_glibc_lds(lds, -absq);
+                const float c = pw * expf_glibc_lds<true>(lds, -absq);      // absq >= 0: no overflow check
                 float cell = 0.f;
                 while (m) {
                     const int k = __builtin_ctzll(m);
@@ -542,7 +542,7 @@ GPIS_DEV float solo_noise3d_value_packed(const DevModel &M, const FastTable &T, 
         const V3 ab = R * pc - R * v3(px, py, pz);
         const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
         const float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
-        const float cv = pw * expf_glibc_lds(lds, -absq);
+        const float cv = pw * expf_glibc_lds<true>(lds, -absq);     // absq >= 0: no overflow check
         for (int g = 0; g < per_pass; ++g) {
             unsigned long long mg = (m >> (g * S)) & cell_bits;
             if (mg == 0ULL)

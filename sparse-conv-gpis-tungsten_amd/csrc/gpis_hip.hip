@@ -1161,7 +1161,10 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
         size_t tb = temp_bytes;
         if (sort_pairs_u32(ws + o_temp, tb, k0, k1, v0, v1, n_active, s) != hipSuccess)
             return set_err(GPIS_ERR_DEVICE, "radix sort failed");
-        k_wave_eval<<<grid_of(n_req, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_req, v1, rays, state, cnt);
+        if (m->host_model.exp_arg_max < 100.f)
+            k_wave_eval<true><<<grid_of(n_req, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_req, v1, rays, state, cnt);
+        else
+            k_wave_eval<false><<<grid_of(n_req, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_req, v1, rays, state, cnt);
         if ((rc = launch_check("k_wave_eval"))) return rc;
         active = v1;            // the sorted requesters are the rays still marching
         n_active = n_req;
@@ -1185,7 +1188,10 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
             size_t tb = temp_bytes;
             if (sort_pairs_u32(ws + o_temp, tb, k0, k1, v0, v1, n, s) != hipSuccess)
                 return set_err(GPIS_ERR_DEVICE, "radix sort failed");
-            k_wave_grad<<<grid_of(n_grad, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_grad, v1, rays, state, cnt);
+            if (m->host_model.exp_arg_max < 100.f)
+                k_wave_grad<true><<<grid_of(n_grad, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_grad, v1, rays, state, cnt);
+            else
+                k_wave_grad<false><<<grid_of(n_grad, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_grad, v1, rays, state, cnt);
             if ((rc = launch_check("k_wave_grad"))) return rc;
         }
         k_wave_finish_sd<<<grid_of(n, 256), 256, 0, s>>>(m->d_model, n, rays, mask, state, out, coeff, cnt);

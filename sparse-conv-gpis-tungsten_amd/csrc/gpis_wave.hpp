@@ -305,6 +305,7 @@ __global__ void __launch_bounds__(kFastBlock) k_wave_tail(const DevModel *__rest
 }
 
 // ---- eval: 64 consecutive sorted requests per wave -------------------------------------------------
+template <bool SMALLARG>
 __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_wave_eval(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n_req,
                                                                         const uint32_t *__restrict__ req, const gpis_ray_in *__restrict__ rays,
                                                                         WaveState *__restrict__ state, Counters *cnt)
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_wave_eval(const D
             }
         } else {
             int gpx;
-            const float v = coop_evaluate_value(M, T, lds, in_cluster, pq, coord, gpx, n_eval);
+            const float v = coop_evaluate_value<SMALLARG>(M, T, lds, in_cluster, pq, coord, gpx, n_eval);
             if (in_cluster) { fv = v; gp = gpx; }
         }
         if (in_cluster)
@@ -387,6 +388,7 @@ __global__ void __launch_bounds__(256) k_wave_grad_keys(const DevModel *__restri
     if ((threadIdx.x & 63) == 0 && rq)
         atomicAdd(req_counter, (unsigned long long)__popcll(rq));
 }
+template <bool SMALLARG>
 __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_wave_grad(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n_req,
                                                                         const uint32_t *__restrict__ req, const gpis_ray_in *__restrict__ rays,
                                                                         WaveState *__restrict__ state, Counters *cnt)
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_wave_grad(const D
         const int lead = __builtin_ctzll(pm);
         const int ax0 = __builtin_amdgcn_readlane(cx, lead), ay0 = __builtin_amdgcn_readlane(cy, lead), az0 = __builtin_amdgcn_readlane(cz, lead);
         const bool in_cluster = pending && cx >= ax0 && cx <= ax0 + 1 && cy >= ay0 && cy <= ay0 + 1 && cz >= az0 && cz <= az0 + 1;
-        const V3 gi = coop_evaluate_gradient(M, T, lds, in_cluster, pq, coord, n_eval);
+        const V3 gi = coop_evaluate_gradient<SMALLARG>(M, T, lds, in_cluster, pq, coord, n_eval);
         if (in_cluster) {
             g = gi;
             pending = false;
