@@ -1,0 +1,378 @@
+// HipSparseConvNoiseMedium.cpp — see the header.  Compiles against the reference's real headers:
+//   g++ -std=c++17 -c -DCONSTEXPR=constexpr -DRAPIDJSON_HAS_STDSTRING=1
+//       -I<ref>/src/core -I<ref>/src/thirdparty -I<ref>/src/thirdparty/eigen -I<ref>/src -I<repo>/include
+// (tests/test_integration_compile.py does exactly that).  Links against libgpis_hip.so.
+#include "HipSparseConvNoiseMedium.hpp"
+
+#include "io/JsonObject.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace Tungsten {
+
+int HipSparseConvNoiseMedium::stringToCorrelationContext(const std::string &name)
+{
+    if (name == "global")
+        return GPIS_CTX_GLOBAL;
+    else if (name == "renewal+")
+        return GPIS_CTX_RENEWAL_PLUS;
+    else if (name == "renewal")
+        return GPIS_CTX_RENEWAL;
+    else if (name == "none")
+        return GPIS_CTX_NONE;
+    FAIL("Invalid correlation context: '%s'", name);
+}
+
+int HipSparseConvNoiseMedium::stringToSamplingScheme1D(const std::string &name)
+{
+    if (name == "uni" || name == "UNI")
+        return GPIS_UNI;
+    else if (name == "nee" || name == "NEE")
+        return GPIS_NEE;
+    else if (name == "mis" || name == "MIS")
+        return GPIS_MIS;
+    FAIL("Invalid sparse conv sampling scheme: '%s'", name);
+}
+
+HipSparseConvNoiseMedium::HipSparseConvNoiseMedium()
+: _handle(nullptr),
+  _device(0),
+  _sigmaA(0.0f),
+  _sigmaS(0.0f),
+  _sigmaT(0.0f),
+  _absorptionOnly(true)
+{
+    gpis_default_params(&_params);     // the reference's defaults (SparseConvolutionNoiseMedium.cpp:17-34)
+}
+
+HipSparseConvNoiseMedium::~HipSparseConvNoiseMedium()
+{
+    teardownAfterRender();
+}
+
+// MeanFunction subclasses, GPFunctions.hpp:867-1005
+void HipSparseConvNoiseMedium::readMean(JsonPtr m, gpis_mean &dst)
+{
+    std::string type = "spherical";
+    m.getField("type", type);
+    if (type == "homogeneous") {
+        dst.type = GPIS_MEAN_HOMOGENEOUS;
+        m.getField("offset", dst.offset);
+    } else if (type == "spherical") {
+        dst.type = GPIS_MEAN_SPHERICAL;
+        Vec3d c(dst.center[0], dst.center[1], dst.center[2]);
+        m.getField("center", c);
+        for (int i = 0; i < 3; ++i) dst.center[i] = c[i];
+        m.getField("radius", dst.radius);
+    } else if (type == "linear") {
+        dst.type = GPIS_MEAN_LINEAR;
+        Vec3d r(dst.center[0], dst.center[1], dst.center[2]), d(dst.dir[0], dst.dir[1], dst.dir[2]);
+        m.getField("reference_point", r);
+        m.getField("direction", d);
+        for (int i = 0; i < 3; ++i) { dst.center[i] = r[i]; dst.dir[i] = d[i]; }
+        m.getField("scale", dst.scale);
+        m.getField("min", dst.min);
+    } else {
+        FAIL("hip_sparse_conv_noise: unsupported mean function type: '%s'", type);
+    }
+}
+
+// SquaredExponentialCovariance::fromJson, GPFunctions.cpp:654-679; "localScale" GPFunctions.hpp:1481-1484
+void HipSparseConvNoiseMedium::readSquaredExponential(JsonPtr c)
+{
+    c.getField("sigma", _params.sigma);
+    c.getField("lengthScale", _params.length_scale);
+    Vec3f aniso(_params.aniso[0], _params.aniso[1], _params.aniso[2]);
+    c.getField("aniso", aniso);
+    for (int i = 0; i < 3; ++i) _params.aniso[i] = aniso[i];
+    bool useMtx = _params.use_aniso_mtx != 0;
+    c.getField("useAnisoMtx", useMtx);
+    _params.use_aniso_mtx = useMtx ? 1 : 0;
+    if (auto mtx = c["anisoMtx"]) {
+        Eigen::Matrix3f a;
+        mtx.get(a);
+        for (int r = 0; r < 3; ++r)
+            for (int col = 0; col < 3; ++col)
+                _params.aniso_mtx[3*r + col] = a(r, col);
+    }
+    c.getField("localScale", _params.local_scale);
+}
+
+// GaussianProcess::fromJson (GaussianProcess.cpp:172-190) for an inline object.  The reference resolves
+// "gaussian_process" through Scene::fetchGaussianProcess, which also accepts the NAME of a process declared
+// at scene level; a maintainer who wants that form adds accessors to GaussianProcess and fills _params from
+// them here (GaussianProcess.hpp keeps _mean/_cov public).
+void HipSparseConvNoiseMedium::readGaussianProcess(JsonPtr gp)
+{
+    if (!gp.isObject())
+        FAIL("hip_sparse_conv_noise: \"gaussian_process\" must be an inline object");
+    if (auto m = gp["mean"])
+        readMean(m, _params.mean);
+    if (auto m = gp["mean_additional"]) {   // GPSampleNodeCSG's second mean (GaussianProcess.cpp:25-39)
+        _params.has_mean_additional = 1;
+        readMean(m, _params.mean_additional);
+    }
+    if (auto c = gp["covariance"]) {
+        std::string type = "squared_exponential";
+        c.getField("type", type);
+        if (type == "squared_exponential") {
+            readSquaredExponential(c);
+        } else if (type == "proc_nonstationary") {      // GPFunctions.cpp:1590-1606, GPFunctions.hpp:2211-2217
+            _params.nonstationary = 1;
+            bool grid = _params.multi_resolution_grid != 0;
+            c.getField("multiResolutionGrid", grid);
+            _params.multi_resolution_grid = grid ? 1 : 0;
+            if (auto inner = c["cov"])
+                readSquaredExponential(inner);
+            if (auto ls = c["ls"]) {                    // ProceduralNoiseVec, GPFunctions.hpp:759-776
+                std::string noise = "bottom_top";
+                ls.getField("noise", noise);
+                if (noise == "bottom_top") _params.ls_ramp_type = GPIS_RAMP_BOTTOM_TOP;
+                else if (noise == "left_right") _params.ls_ramp_type = GPIS_RAMP_LEFT_RIGHT;
+                else if (noise == "front_back") _params.ls_ramp_type = GPIS_RAMP_FRONT_BACK;
+                else FAIL("hip_sparse_conv_noise: unsupported \"ls\" noise type: '%s'", noise);
+                ls.getField("min", _params.ls_min);
+                ls.getField("max", _params.ls_max);
+                ls.getField("start", _params.ls_start);
+                ls.getField("end", _params.ls_end);
+            }
+        } else {
+            FAIL("hip_sparse_conv_noise: unsupported covariance type: '%s'", type);
+        }
+    }
+}
+
+void HipSparseConvNoiseMedium::fromJson(JsonPtr value, const Scene &scene)
+{
+    Medium::fromJson(value, scene);      // phase_function, transmittance, max_bounces (Medium.cpp:29-38)
+    _params.max_bounces = _maxBounce;
+
+    // GaussianProcessMedium::fromJson, GaussianProcessMedium.cpp:97-126
+    Vec3f sa(_params.sigma_a[0], _params.sigma_a[1], _params.sigma_a[2]);
+    Vec3f ss(_params.sigma_s[0], _params.sigma_s[1], _params.sigma_s[2]);
+    value.getField("sigma_a", sa);
+    value.getField("sigma_s", ss);
+    for (int i = 0; i < 3; ++i) { _params.sigma_a[i] = sa[i]; _params.sigma_s[i] = ss[i]; }
+    value.getField("density", _params.density);
+    std::string ctxtString = "goldfish";
+    value.getField("correlation_context", ctxtString);
+    _params.correlation_context = stringToCorrelationContext(ctxtString);
+    if (auto gp = value["gaussian_process"])
+        readGaussianProcess(gp);
+    _phaseFunctions.clear();
+    _phaseFunctions.push_back(_phaseFunction);     // "We always have the default one"
+
+    // SparseConvolutionNoiseMedium::fromJson, SparseConvolutionNoiseMedium.cpp:57-73
+    value.getField("step_size", _params.step_size);
+    value.getField("min_step", _params.min_step);
+    value.getField("seed", _params.seed);
+    value.getField("impulse_density", _params.impulse_density);
+    auto flag = [&](const char *key, int32_t &dst) {
+        bool b = dst != 0;
+        value.getField(key, b);
+        dst = b ? 1 : 0;
+    };
+    flag("single_realization", _params.single_realization);
+    flag("isotropic_3D_sampling", _params.isotropic_3d_sampling);
+    flag("1D_sampling", _params.sampling_1d);
+    std::string scheme1DString = "uni";
+    value.getField("1D_sampling_scheme", scheme1DString);
+    _params.scheme_1d = stringToSamplingScheme1D(scheme1DString);
+    flag("1D_gradient_correlationXY", _params.correlation_xy);
+    flag("surf_vol_phase_separate", _params.surf_vol_phase_separate);
+    value.getField("surf_vol_phase_amp_thresh", _params.surf_vol_phase_amp_thresh);
+    int device = _device;
+    value.getField("hip_device", device);
+    _device = device;
+}
+
+rapidjson::Value HipSparseConvNoiseMedium::toJson(Allocator &allocator) const
+{
+    static const char *ctxNames[] = {"global", "renewal+", "renewal", "none"};
+    static const char *schemeNames[] = {"uni", "nee", "mis"};
+    return JsonObject{Medium::toJson(allocator), allocator,
+        "type", "hip_sparse_conv_noise",
+        "sigma_a", Vec3f(_params.sigma_a[0], _params.sigma_a[1], _params.sigma_a[2]),
+        "sigma_s", Vec3f(_params.sigma_s[0], _params.sigma_s[1], _params.sigma_s[2]),
+        "density", _params.density,
+        "correlation_context", ctxNames[_params.correlation_context],
+        "step_size", _params.step_size,
+        "min_step", _params.min_step,
+        "seed", _params.seed,
+        "impulse_density", _params.impulse_density,
+        "single_realization", _params.single_realization != 0,
+        "isotropic_3D_sampling", _params.isotropic_3d_sampling != 0,
+        "1D_sampling", _params.sampling_1d != 0,
+        "1D_sampling_scheme", schemeNames[_params.scheme_1d],
+        "1D_gradient_correlationXY", _params.correlation_xy != 0,
+        "surf_vol_phase_separate", _params.surf_vol_phase_separate != 0,
+        "surf_vol_phase_amp_thresh", _params.surf_vol_phase_amp_thresh
+    };
+}
+
+void HipSparseConvNoiseMedium::prepareForRender()
+{
+    teardownAfterRender();
+    _sigmaA = Vec3f(_params.sigma_a[0], _params.sigma_a[1], _params.sigma_a[2])*_params.density;
+    _sigmaS = Vec3f(_params.sigma_s[0], _params.sigma_s[1], _params.sigma_s[2])*_params.density;
+    _sigmaT = _sigmaA + _sigmaS;
+    _absorptionOnly = _sigmaS == 0.0f;
+    if (gpis_create(&_params, _device, &_handle) != GPIS_OK) {
+        _handle = nullptr;
+        FAIL("hip_sparse_conv_noise: gpis_create failed: %s", gpis_last_error());
+    }
+}
+
+void HipSparseConvNoiseMedium::teardownAfterRender()
+{
+    if (_handle)
+        gpis_destroy(_handle);
+    _handle = nullptr;
+}
+
+void HipSparseConvNoiseMedium::fillRay(const Ray &ray, const MediumState &state, float u, gpis_ray_in &r) const
+{
+    std::memset(&r, 0, sizeof r);
+    for (int i = 0; i < 3; ++i) {
+        r.pos[i] = ray.pos()[i];
+        r.dir[i] = ray.dir()[i];
+        r.last_aniso[i] = state.lastAniso[i];
+    }
+    r.near_t = ray.nearT();
+    r.far_t = ray.farT();
+    r.pixel[0] = state.info.pixelSampleSegment.x();
+    r.pixel[1] = state.info.pixelSampleSegment.y();
+    r.spp = state.info.pixelSampleSegment.z();
+    r.segment = state.info.pixelSampleSegment.w();
+    r.scene_seed = state.info.sceneSeed;
+    r.info_t = state.info.t;
+    r.u_jitter = u;
+    r.first_scatter = state.firstScatter ? 1u : 0u;
+    r.bounce = state.bounce;
+    r.last_val = state.lastVal;
+    r.last_gp_id = state.lastGPId;
+}
+
+// GaussianProcessMedium::sampleDistance, GaussianProcessMedium.cpp:221-341: the march, the gradient and the
+// validity checks run on the device; the MediumState / MediumSample writes below are the reference's.
+bool HipSparseConvNoiseMedium::sampleDistance(PathSampleGenerator &sampler, const Ray &ray,
+        MediumState &state, MediumSample &sample) const
+{
+    sample.emission = Vec3f(0.0f);
+    if (state.bounce >= _maxBounce)
+        return false;
+
+    float maxT = ray.farT();
+    if (!std::isfinite(maxT))
+        maxT = float(double(ray.nearT()) + 2000);
+    if (maxT == 0.f) {
+        sample.t = maxT;
+        sample.weight = Vec3f(1.f);
+        sample.pdf = 1.0f;
+        sample.exited = true;
+        sample.p = ray.pos() + sample.t*ray.dir();
+        sample.phase = _phaseFunction.get();
+        sample.sparseConv1DSamplingScheme = SparseConv1DSamplingScheme::UNI;
+        return true;
+    }
+    if (_absorptionOnly && ray.farT() == Ray::infinity())
+        return false;
+
+    gpis_ray_in r;
+    gpis_seg_out o;
+    auto ctxt = std::make_shared<GPContextHip>();
+    ctxt->medium = this;
+    fillRay(ray, state, sampler.next1D(), r);     // the path's ONE next1D() (SparseConvolutionNoiseMedium.cpp:129)
+    if (gpis_sample_distance_host(_handle, 1, &r, &o, &ctxt->coeff) != GPIS_OK)
+        FAIL("gpis_sample_distance_host: %s", gpis_last_error());
+
+    // intersectGP's state writes (SparseConvolutionNoiseMedium.cpp:162-181) and sampleDistance's own
+    state.gpContext = ctxt;
+    state.lastGPId = o.gp_id;
+    state.lastVal = o.last_val;
+    state.sparseConv1DSamplingScheme = SparseConv1DSamplingScheme(o.scheme);
+    sample.exited = o.exited != 0;
+    if (_absorptionOnly) {
+        // GaussianProcessMedium.cpp:250-258: the weight is transmittance(), which writes lastAniso / firstScatter
+        // on a hit only (:371-381) — o.aniso is the incoming lastAniso otherwise; sample.aniso stays untouched
+        state.lastAniso = Vec3d(o.aniso[0], o.aniso[1], o.aniso[2]);
+        if (o.weight[0] == 0.f)
+            state.firstScatter = false;
+    } else {
+        state.lastAniso = sample.aniso = Vec3d(o.aniso[0], o.aniso[1], o.aniso[2]);
+        state.firstScatter = false;
+    }
+    if (!o.ok)
+        return false;
+
+    sample.t = o.sample_t;
+    sample.continuedT = o.continued_t;
+    sample.weight = Vec3f(o.weight[0], o.weight[1], o.weight[2]);
+    sample.continuedWeight = Vec3f(o.continued_weight[0], o.continued_weight[1], o.continued_weight[2]);
+    sample.pdf = 1.0f;
+    sample.sparseConv1DSamplingScheme = SparseConv1DSamplingScheme(o.scheme);
+    if (!_absorptionOnly)
+        state.advance();
+    sample.p = Vec3f(o.p[0], o.p[1], o.p[2]);
+    sample.phase = _phaseFunctions[size_t(state.lastGPId) < _phaseFunctions.size() ? state.lastGPId : 0].get();
+    sample.gpId = state.lastGPId;
+    sample.ctxt = state.gpContext.get();
+    state.info.t += sample.t;
+    sample.rayInfo = state.info;
+    return true;
+}
+
+// GaussianProcessMedium::transmittance, GaussianProcessMedium.cpp:343-393
+Vec3f HipSparseConvNoiseMedium::transmittance(PathSampleGenerator &sampler, const Ray &ray, bool /*startOnSurface*/,
+        bool /*endOnSurface*/, MediumState *state) const
+{
+    gpis_ray_in r;
+    uint8_t visible = 0;
+    fillRay(ray, *state, sampler.next1D(), r);
+    if (gpis_transmittance_host(_handle, 1, &r, &visible) != GPIS_OK)
+        return Vec3f(0.0f);
+    state->firstScatter = false;
+    return visible ? Vec3f(1.0f) : Vec3f(0.0f);
+}
+
+static void fillNee(const Vec3f &rayDir, const Vec3f &normal, const Vec3f &p, float tSegment, const RayInfo &info,
+        const gpis_cond_coeff &coeff, gpis_nee_query &q)
+{
+    std::memset(&q, 0, sizeof q);
+    for (int i = 0; i < 3; ++i) {
+        q.ray_dir[i] = rayDir[i];
+        q.normal[i] = normal[i];
+        q.p[i] = p[i];
+    }
+    q.t_segment = tSegment;
+    q.info_t = info.t;
+    q.pixel[0] = info.pixelSampleSegment.x();
+    q.pixel[1] = info.pixelSampleSegment.y();
+    q.spp = info.pixelSampleSegment.z();
+    q.segment = info.pixelSampleSegment.w();
+    q.scene_seed = info.sceneSeed;
+    q.coeff = coeff;
+}
+
+float GPContextHip::neePDF(const Vec3f &rayDir, const Vec3f &normal, const Vec3f &p, float tSegment, const RayInfo &info) const
+{
+    gpis_nee_query q;
+    fillNee(rayDir, normal, p, tSegment, info, coeff, q);
+    float pdf = 0.0f;
+    if (gpis_nee_pdf_host(medium->handle(), 1, &q, &pdf) != GPIS_OK)
+        FAIL("gpis_nee_pdf_host: %s", gpis_last_error());
+    return pdf;
+}
+
+Vec3f GPContextHip::neeGrad(const Vec3f &rayDir, const Vec3f &normal, const Vec3f &p, const RayInfo &info) const
+{
+    gpis_nee_query q;
+    fillNee(rayDir, normal, p, 0.0f, info, coeff, q);
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    if (gpis_nee_grad_host(medium->handle(), 1, &q, g) != GPIS_OK)
+        FAIL("gpis_nee_grad_host: %s", gpis_last_error());
+    return Vec3f(g[0], g[1], g[2]);
+}
+
+}
