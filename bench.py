@@ -96,6 +96,71 @@ def cpu_baseline(pkg, params, cores):
     }
 
 
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks ourselves, as CHILD processes of a
+    parent that never touches the GPU (no torch.cuda call, no libgpis call: a process that has initialised the
+    GPU must not exec or fork GPU workers), with the launcher the driver would use, and relay rank 0's one JSON
+    line and the job's exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in proc.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif proc.returncode == 0:
+        print("bench.py launcher: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def dry_run(args, world, rank):
+    """Launcher / sharding self-test without a GPU (tests/test_bench_launcher.py): the same process-group set-up,
+    parameter broadcast, tile-row sharding and reduce as the real run, over gloo, with a renderer that writes a
+    known function of the pixel index — so rank 0 can check that every pixel was rendered exactly once."""
+    import torch
+    import torch.distributed as dist
+    import _gpis_pkg
+    pkg = _gpis_pkg.load_package()        # numpy mirrors only: the library is not loaded
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    params = pkg.params_for_config(args.config) if rank == 0 else np.zeros((), dtype=pkg.PARAMS)
+    params = pkg.dist.broadcast_params(params, pkg.PARAMS, dist)
+    W, H, spp = args.width, args.height, args.spp
+    scene = pkg.default_scene_s(W, H, spp)
+    rad = torch.zeros(H * W, dtype=torch.float32)
+
+    def render_into(part, acc):
+        k = int(part["spp_count"])
+        for y in pkg.dist.shard_rows(part, int(part["shard_index"]), max(int(part["shard_count"]), 1), int(part["tile_size"])):
+            idx = torch.arange(y * W, (y + 1) * W)
+            acc[idx] += (1 + idx % 7).to(torch.float32) * k
+
+    pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard)
+    if rank == 0:
+        idx = torch.arange(H * W)
+        want = (1 + idx % 7).to(torch.float32) * pkg.dist.total_spp(scene, world, args.shard)
+        print(json.dumps({"metric": "dry-run (no GPU work)", "dry_run": True, "value": None, "n_gpus": world,
+                          "ranks_seen": dist.get_world_size() if world > 1 else 1, "shard": args.shard,
+                          "coverage_ok": bool(torch.equal(rad, want)), "impulse_density": float(params["impulse_density"])}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,23 +170,33 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--shard", choices=["spp", "rows"], default="spp")
+    ap.add_argument("--shard", choices=["rows", "spp"], default="rows",
+                    help="rows: 16-pixel tile rows dealt round-robin to the ranks — the tile split of the reference's "
+                         "integrator, the SAME image at every N (strong scaling); spp: every rank renders its own spp "
+                         "slice of every pixel (weak scaling, N times the samples)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / sharding self-test over gloo on CPU: no GPU work, no metric")
     ap.add_argument("--guide", default="16:64", help="certified guide field 'half_extent_cells:points_per_cell' for "
                     "single-realization media, or 'off' (built once before the timed region: 34 GB / 3.3 s at 16:64, "
                     "4.3 GB / 0.3 s at 16:32; falls back to 16:32 if the allocation fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the driver starts it (`python bench.py --gpus N`): become the launcher
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
     import torch
     import torch.distributed as dist
     import _gpis_pkg
     pkg = _gpis_pkg.load_package()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -205,7 +280,7 @@ def main():
         kernel = ("k_guided_" if guide_info else ("k_fast_" if fast else "k_")) + names[dom]
         res = {
             "metric": "Msamples/s (primary rays x spp / s)", "value": total_samples / dt_max / 1e6, "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+            "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.shard == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: scene S %dx%d, %d spp/GPU, SparseConvolutionNoiseMedium (3D isotropic, "
                                    "impulse_density=%d, ctx=renewal, single_realization)" % (args.config, W, H, spp, int(params["impulse_density"]))

@@ -354,7 +354,10 @@ typedef struct gpis_scene_s {
     float bound_radius;               /* 1.5 */
     float light_dir[3];               /* (0.5,0.7,0.5)/|.| (normalised by the driver) */
     float light_radiance;             /* 1 */
-    uint32_t y_begin, y_count;        /* image rows rendered by this call (tile-row sharding) */
+    uint32_t y_begin, y_count;        /* image rows this call covers */
+    uint32_t shard_index, shard_count; /* shard_count > 1: of those rows, only the tile rows t (tile_size pixels high, counted
+                                          from y_begin) with t % shard_count == shard_index — the interleaved tile-row split of
+                                          the multi-GPU driver; 0 or 1 = all rows */
 } gpis_scene_s;
 
 void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp);

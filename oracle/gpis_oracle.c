@@ -1832,6 +1832,7 @@ void oracle_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, ui
     s->light_dir[0] = 0.5f; s->light_dir[1] = 0.7f; s->light_dir[2] = 0.5f;
     s->light_radiance = 1.f;
     s->y_begin = 0; s->y_count = height;
+    s->shard_index = 0; s->shard_count = 1;
 }
 
 /* ray / sphere(|x| = R) intersection in double; returns 0 on miss */
@@ -1916,6 +1917,12 @@ static int scene_s_shadow_ray(const gpis_scene_s *s, const gpis_ray_in *prim, co
     return 1;
 }
 
+/* gpis_scene_s::shard_index/shard_count (include/gpis.h): tile rows counted from y_begin, dealt round-robin */
+static int scene_row_in_shard(const gpis_scene_s *s, uint32_t py)
+{
+    if (s->shard_count <= 1u) return 1;
+    return ((py - s->y_begin) / s->tile_size) % s->shard_count == s->shard_index;
+}
 typedef struct { const gpis_scene_s *s; float *rad; uint32_t *hits; } render_ctx;
 static void render_range(oracle_medium *m, oracle_counters *cnt, size_t i0, size_t i1, void *c)
 {
@@ -1923,6 +1930,7 @@ static void render_range(oracle_medium *m, oracle_counters *cnt, size_t i0, size
     const gpis_scene_s *s = x->s;
     for (size_t idx = i0; idx < i1; ++idx) {
         uint32_t py = s->y_begin + (uint32_t)(idx / s->width), px = (uint32_t)(idx % s->width);
+        if (!scene_row_in_shard(s, py)) continue;
         float acc = 0.f;
         uint32_t hits = 0;
         for (uint32_t k = 0; k < s->spp_count; ++k) {
@@ -1951,6 +1959,7 @@ int oracle_render_scene_s(oracle_medium *m, const gpis_scene_s *s, float *radian
 {
     if (!m || !s || !radiance_sum) return fail("null argument");
     if (s->y_begin + s->y_count > s->height) return fail("row range outside the image");
+    if (s->shard_count > 1u && (s->shard_index >= s->shard_count || s->tile_size == 0)) return fail("bad shard");
     render_ctx c = {s, radiance_sum, hit_count};
     parallel_for(m, (size_t)s->y_count * s->width, render_range, &c);
     return GPIS_OK;
@@ -2065,6 +2074,7 @@ static void paths_range(oracle_medium *m, oracle_counters *cnt, size_t i0, size_
     const gpis_scene_s *s = x->s;
     for (size_t idx = i0; idx < i1; ++idx) {
         uint32_t py = s->y_begin + (uint32_t)(idx / s->width), px = (uint32_t)(idx % s->width);
+        if (!scene_row_in_shard(s, py)) continue;
         float acc = 0.f;
         for (uint32_t k = 0; k < s->spp_count; ++k)
             acc += scene_paths_sample(m, cnt, s, px, py, s->spp_begin + k, x->max_bounces, x->albedo);
@@ -2075,6 +2085,7 @@ int oracle_render_scene_s_paths(oracle_medium *m, const gpis_scene_s *s, int max
 {
     if (!m || !s || !radiance_sum || max_path_bounces < 1) return fail("bad argument");
     if (s->y_begin + s->y_count > s->height) return fail("row range outside the image");
+    if (s->shard_count > 1u && (s->shard_index >= s->shard_count || s->tile_size == 0)) return fail("bad shard");
     paths_ctx c = {s, radiance_sum, max_path_bounces, albedo};
     parallel_for(m, (size_t)s->y_count * s->width, paths_range, &c);
     return GPIS_OK;
@@ -2229,6 +2240,7 @@ static void nee_scene_range(oracle_medium *m, oracle_counters *cnt, size_t i0, s
     const gpis_scene_s *s = x->s;
     for (size_t idx = i0; idx < i1; ++idx) {
         uint32_t py = s->y_begin + (uint32_t)(idx / s->width), px = (uint32_t)(idx % s->width);
+        if (!scene_row_in_shard(s, py)) continue;
         float acc = 0.f;
         for (uint32_t k = 0; k < s->spp_count; ++k)
             acc += scene_nee_sample(m, cnt, s, x->sf, px, py, s->spp_begin + k);
@@ -2239,6 +2251,7 @@ int oracle_render_scene_s_nee(oracle_medium *m, const gpis_scene_s *s, const gpi
 {
     if (!m || !s || !surf || !radiance_sum) return fail("null argument");
     if (s->y_begin + s->y_count > s->height) return fail("row range outside the image");
+    if (s->shard_count > 1u && (s->shard_index >= s->shard_count || s->tile_size == 0)) return fail("bad shard");
     if (!(surf->cap_cos < 1.0f) || !(surf->cap_cos > -1.0f)) return fail("cap_cos must lie in (-1, 1)");
     nee_scene_ctx c = {s, surf, radiance_sum};
     parallel_for(m, (size_t)s->y_count * s->width, nee_scene_range, &c);

@@ -86,12 +86,23 @@ SCENE_S = np.dtype([
     ("scene_seed", "<u4"), ("tile_size", "<u4"),
     ("cam_pos", "<f4", 3), ("cam_fov_deg", "<f4"), ("bound_radius", "<f4"),
     ("light_dir", "<f4", 3), ("light_radiance", "<f4"),
-    ("y_begin", "<u4"), ("y_count", "<u4"),
+    ("y_begin", "<u4"), ("y_count", "<u4"), ("shard_index", "<u4"), ("shard_count", "<u4"),
 ], align=True)
 
 SURFACE_S = np.dtype([
     ("eta", "<f4"), ("k", "<f4"), ("albedo", "<f4"), ("cap_cos", "<f4"), ("cap_radiance", "<f4"), ("_pad", "<f4", 3),
 ], align=True)
+
+
+def default_scene_s(width, height, spp):
+    """gpis_default_scene_s (scene S of SURVEY.md 8d) without loading the library."""
+    s = np.zeros((), dtype=SCENE_S)
+    s["width"], s["height"], s["spp_begin"], s["spp_count"] = width, height, 0, spp
+    s["scene_seed"], s["tile_size"] = 0xBA5EBA11, 16
+    s["cam_pos"], s["cam_fov_deg"], s["bound_radius"] = (0.0, 0.0, 4.0), 35.0, 1.5
+    s["light_dir"], s["light_radiance"] = (0.5, 0.7, 0.5), 1.0
+    s["y_begin"], s["y_count"], s["shard_index"], s["shard_count"] = 0, height, 0, 1
+    return s
 
 
 def default_surface_s():

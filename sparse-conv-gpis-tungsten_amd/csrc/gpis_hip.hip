@@ -61,6 +61,34 @@ struct SceneConst {   // host-precomputed scene-S constants (host libm: tanf, no
     float light[3];
 };
 
+// Pixel `local` of a driver call -> index y*width + x in the image.  A call renders the image rows
+// [y_begin, y_begin + y_count); with shard_count > 1 only the tile rows t (tile_size pixels high, counted
+// from y_begin) with t % shard_count == shard_index — the interleaved tile-row split of the multi-GPU
+// driver, kept in ONE batch per rank so that every stage stays one launch.
+__host__ __device__ inline size_t scene_pixel(const gpis_scene_s &s, size_t local)
+{
+    if (s.shard_count <= 1u)
+        return (size_t)s.y_begin * s.width + local;
+    const size_t ly = local / s.width, x = local % s.width;
+    const size_t lt = ly / s.tile_size, r = ly % s.tile_size;
+    return ((size_t)s.y_begin + (lt * s.shard_count + s.shard_index) * s.tile_size + r) * s.width + x;
+}
+// rows this call renders
+static size_t scene_rows(const gpis_scene_s &s)
+{
+    if (s.shard_count <= 1u)
+        return s.y_count;
+    size_t rows = 0;
+    for (size_t t = s.shard_index, y0 = (size_t)s.shard_index * s.tile_size; y0 < s.y_count; t += s.shard_count, y0 = t * s.tile_size)
+        rows += (s.y_count - y0 < s.tile_size) ? s.y_count - y0 : s.tile_size;
+    return rows;
+}
+static bool scene_args_ok(const gpis_scene_s *s)
+{
+    return s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height &&
+           (s->shard_count <= 1u || (s->shard_index < s->shard_count && s->tile_size > 0));
+}
+
 struct gpis_medium {
     gpis_params params;
     DevModel host_model;
@@ -454,7 +482,7 @@ __global__ void __launch_bounds__(256) k_scene_primary(SceneConst sc, size_t fir
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_samples) return;
     const gpis_scene_s &s = sc.s;
-    size_t pix = first_pixel + i / s.spp_count;
+    size_t pix = scene_pixel(s, first_pixel + i / s.spp_count);
     uint32_t k = (uint32_t)(i % s.spp_count);
     uint32_t x = (uint32_t)(pix % s.width), y = (uint32_t)(pix / s.width);
     uint32_t spp = s.spp_begin + k;
@@ -543,8 +571,9 @@ __global__ void __launch_bounds__(256) k_scene_accumulate(SceneConst sc, size_t 
         if (valid2[i])
             acc += cosl[i] * (vis[i] ? 1.f : 0.f) * sc.s.light_radiance;
     }
-    radiance_sum[first_pixel + j] += acc;
-    if (hit_count) hit_count[first_pixel + j] += hits;
+    const size_t pix = scene_pixel(sc.s, first_pixel + j);
+    radiance_sum[pix] += acc;
+    if (hit_count) hit_count[pix] += hits;
 }
 
 
@@ -568,7 +597,7 @@ __global__ void __launch_bounds__(256) k_paths_begin(SceneConst sc, size_t first
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_samples) return;
     const gpis_scene_s &s = sc.s;
-    size_t pix = first_pixel + i / s.spp_count;
+    size_t pix = scene_pixel(s, first_pixel + i / s.spp_count);
     uint32_t k = (uint32_t)(i % s.spp_count);
     uint32_t x = (uint32_t)(pix % s.width), y = (uint32_t)(pix / s.width);
     uint32_t spp = s.spp_begin + k;
@@ -745,15 +774,16 @@ __global__ void __launch_bounds__(256) k_paths_nee_add(size_t n_samples, PathArr
     a.emission[order ? (size_t)order[j] : j] += vis[k] ? a.contrib[j] : 0.f;
 }
 
-__global__ void __launch_bounds__(256) k_paths_accumulate(uint32_t spp, size_t first_pixel, size_t n_pixels, const float *__restrict__ emission,
+__global__ void __launch_bounds__(256) k_paths_accumulate(SceneConst sc, size_t first_pixel, size_t n_pixels, const float *__restrict__ emission,
                                                           float *__restrict__ radiance_sum)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_pixels) return;
+    const uint32_t spp = sc.s.spp_count;
     float acc = 0.f;
     for (uint32_t k = 0; k < spp; ++k)
         acc += emission[j * spp + k];
-    radiance_sum[first_pixel + j] += acc;
+    radiance_sum[scene_pixel(sc.s, first_pixel + j)] += acc;
 }
 
 // --------------------------------------------------------------------------------------
@@ -1615,6 +1645,7 @@ extern "C" void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t h
     s->light_dir[0] = 0.5f; s->light_dir[1] = 0.7f; s->light_dir[2] = 0.5f;
     s->light_radiance = 1.f;
     s->y_begin = 0; s->y_count = height;
+    s->shard_index = 0; s->shard_count = 1;
 }
 
 // Samples per chunk of the tile drivers: 2^default_log2 unless GPIS_CHUNK_LOG2 says otherwise.  Chunks are
@@ -1661,13 +1692,12 @@ static SceneConst make_scene_const(const gpis_scene_s *s)
 extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum, uint32_t *hit_count, void *stream)
 {
     CHECK_ARGS(m && s && radiance_sum);
-    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
+    CHECK_ARGS(scene_args_ok(s));
     std::lock_guard<std::mutex> lock(m->mu);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = (hipStream_t)stream;
     SceneConst sc = make_scene_const(s);
-    const size_t total_pixels = (size_t)s->y_count * s->width;
-    const size_t first_pixel0 = (size_t)s->y_begin * s->width;
+    const size_t total_pixels = scene_rows(*s) * s->width;
     // workspace: [prim rays | seg out | shadow rays | u_shadow | cosl | valid | valid2 | vis | hit], ≈375 B per sample;
     // the largest chunk the device can hold, starting from the whole frame (2^27 samples ≈ 50 GB)
     size_t chunk_pixels = 0, ns_max = 0, off = 0;
@@ -1695,13 +1725,13 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
     for (size_t p0 = 0; p0 < total_pixels; p0 += chunk_pixels) {
         size_t np = total_pixels - p0 < chunk_pixels ? total_pixels - p0 : chunk_pixels;
         size_t ns = np * s->spp_count;
-        k_scene_primary<<<grid_of(ns, 256), 256, 0, st>>>(sc, first_pixel0 + p0, ns, prim, us, v1);
+        k_scene_primary<<<grid_of(ns, 256), 256, 0, st>>>(sc, p0, ns, prim, us, v1);
         if ((rc = launch_check("k_scene_primary"))) return rc;
         if ((rc = sample_distance_impl(m, ns, prim, seg, nullptr, v1, st))) return rc;
         k_scene_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, ns, prim, seg, us, v1, sh, cosl, v2, hit);
         if ((rc = launch_check("k_scene_shade"))) return rc;
         if ((rc = transmittance_impl(m, ns, sh, vis, v2, st))) return rc;
-        k_scene_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, first_pixel0 + p0, np, cosl, v2, vis, hit, radiance_sum, hit_count);
+        k_scene_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, p0, np, cosl, v2, vis, hit, radiance_sum, hit_count);
         if ((rc = launch_check("k_scene_accumulate"))) return rc;
     }
     return GPIS_OK;
@@ -1710,13 +1740,12 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
 extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, int max_path_bounces, float albedo, float *radiance_sum, void *stream)
 {
     CHECK_ARGS(m && s && radiance_sum && max_path_bounces >= 1);
-    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
+    CHECK_ARGS(scene_args_ok(s));
     std::lock_guard<std::mutex> lock(m->mu);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = (hipStream_t)stream;
     SceneConst sc = make_scene_const(s);
-    const size_t total_pixels = (size_t)s->y_count * s->width;
-    const size_t first_pixel0 = (size_t)s->y_begin * s->width;
+    const size_t total_pixels = scene_rows(*s) * s->width;
     size_t chunk_pixels = ((size_t)1 << chunk_log2(25)) / s->spp_count;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
@@ -1757,7 +1786,7 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
     for (size_t p0 = 0; p0 < total_pixels; p0 += chunk_pixels) {
         size_t np = total_pixels - p0 < chunk_pixels ? total_pixels - p0 : chunk_pixels;
         size_t ns = np * s->spp_count;
-        k_paths_begin<<<grid_of(ns, 256), 256, 0, st>>>(sc, first_pixel0 + p0, ns, a);
+        k_paths_begin<<<grid_of(ns, 256), 256, 0, st>>>(sc, p0, ns, a);
         if ((rc = launch_check("k_paths_begin"))) return rc;
         // the segment of bounce max-1 cannot contribute (no NEE there, TraceBase.cpp:546, and the
         // light is a Dirac delta), so it is not traced
@@ -1800,7 +1829,7 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
             }
             if ((rc = launch_check("k_paths_nee_add"))) return rc;
         }
-        k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(s->spp_count, first_pixel0 + p0, np, a.emission, radiance_sum);
+        k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, p0, np, a.emission, radiance_sum);
         if ((rc = launch_check("k_paths_accumulate"))) return rc;
     }
     return GPIS_OK;
@@ -1809,14 +1838,13 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
 extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, const gpis_surface_s *surf, float *radiance_sum, void *stream)
 {
     CHECK_ARGS(m && s && surf && radiance_sum);
-    CHECK_ARGS(s->width > 0 && s->height > 0 && s->spp_count > 0 && s->y_begin + s->y_count <= s->height);
+    CHECK_ARGS(scene_args_ok(s));
     CHECK_ARGS(surf->cap_cos < 1.0f && surf->cap_cos > -1.0f);
     std::lock_guard<std::mutex> lock(m->mu);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = (hipStream_t)stream;
     SceneConst sc = make_scene_const(s);
-    const size_t total_pixels = (size_t)s->y_count * s->width;
-    const size_t first_pixel0 = (size_t)s->y_begin * s->width;
+    const size_t total_pixels = scene_rows(*s) * s->width;
     size_t chunk_pixels = ((size_t)1 << chunk_log2(24)) / s->spp_count;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
@@ -1847,7 +1875,7 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
     for (size_t p0 = 0; p0 < total_pixels; p0 += chunk_pixels) {
         size_t np = total_pixels - p0 < chunk_pixels ? total_pixels - p0 : chunk_pixels;
         size_t ns = np * s->spp_count;
-        k_paths_begin<<<grid_of(ns, 256), 256, 0, st>>>(sc, first_pixel0 + p0, ns, a);
+        k_paths_begin<<<grid_of(ns, 256), 256, 0, st>>>(sc, p0, ns, a);
         if ((rc = launch_check("k_paths_begin"))) return rc;
         if ((rc = sample_distance_impl(m, ns, a.rays, a.seg, b.coeff, a.alive, st))) return rc;
         k_nee_setup<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);
@@ -1862,7 +1890,7 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
         if ((rc = transmittance_impl(m, ns, b.shadow_phase, b.vis_phase, b.go_phase, st))) return rc;
         k_nee_gather<<<grid_of(ns, 256), 256, 0, st>>>(surf->cap_radiance, ns, a, b);
         if ((rc = launch_check("k_nee_gather"))) return rc;
-        k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(s->spp_count, first_pixel0 + p0, np, a.emission, radiance_sum);
+        k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, p0, np, a.emission, radiance_sum);
         if ((rc = launch_check("k_paths_accumulate"))) return rc;
     }
     return GPIS_OK;

@@ -8,8 +8,10 @@ while marching.  Two shardings are provided:
   "spp"   rank r renders sample indices [r*spp, (r+1)*spp) of every pixel (per-GPU work fixed →
           weak scaling); the per-rank radiance sums are added with ONE reduce(sum) to rank 0.
   "rows"  the image's 16-pixel tile rows (PathTraceIntegrator.hpp:27) are dealt round-robin to the
-          ranks (total work fixed → strong scaling); partial images are disjoint, so the same
-          reduce(sum) assembles them (a gather of disjoint tiles expressed as a sum of zeros).
+          ranks (total work fixed → strong scaling, the same image at every world size); each rank
+          renders its rows as ONE batch (gpis_scene_s.shard_index / shard_count); partial images are
+          disjoint, so the same reduce(sum) assembles them (a gather of disjoint tiles expressed as
+          a sum of zeros).
 
 Both need exactly two collectives per job: the broadcast of the POD parameter block from rank 0
 and the final reduce.  `render_fn(scene_record) -> radiance tensor/array` is injected so that the
@@ -45,16 +47,20 @@ def shard_scene(scene, rank, world, mode="spp", tile=16):
         part["spp_begin"] = int(scene["spp_begin"]) + rank * spp
         return [part]
     if mode == "rows":
-        parts = []
-        h = int(scene["height"])
-        for t, y0 in enumerate(range(0, h, tile)):
-            if t % world == rank:
-                part = scene.copy()
-                part["y_begin"] = y0
-                part["y_count"] = min(tile, h - y0)
-                parts.append(part)
-        return parts
+        # ONE record per rank: the driver itself walks the rank's interleaved tile rows (gpis_scene_s.shard_*),
+        # so every stage of the frame stays a single launch per rank
+        part = scene.copy()
+        part["tile_size"] = tile
+        part["shard_index"] = rank
+        part["shard_count"] = world
+        return [part]
     raise ValueError("unknown sharding mode %r" % mode)
+
+
+def shard_rows(scene, rank, world, tile=16):
+    """Image rows of rank `rank` under the "rows" sharding (for tests and bookkeeping)."""
+    y0, n = int(scene["y_begin"]), int(scene["y_count"])
+    return [y0 + y for y in range(n) if world <= 1 or (y // tile) % world == rank]
 
 
 def total_spp(scene, world, mode):

@@ -73,8 +73,11 @@ def test_shard_scene_partitions(pkg, ob):
     for world in (1, 2, 3, 8):
         rows = np.zeros(50, dtype=int)
         for r in range(world):
-            for part in pkg.dist.shard_scene(scene, r, world, "rows"):
-                rows[int(part["y_begin"]):int(part["y_begin"]) + int(part["y_count"])] += 1
+            parts = pkg.dist.shard_scene(scene, r, world, "rows")
+            assert len(parts) == 1          # one batch per rank
+            if world > 1:
+                assert int(parts[0]["shard_index"]) == r and int(parts[0]["shard_count"]) == world
+            rows[pkg.dist.shard_rows(scene, r, world)] += 1
         assert (rows == 1).all()
         begins = sorted(int(pkg.dist.shard_scene(scene, r, world, "spp")[0]["spp_begin"]) for r in range(world))
         assert begins == [4 * r for r in range(world)]

@@ -35,6 +35,16 @@ def test_c1_full_frame_properties(pkg, ob):
     order = rows[0::3] + rows[1::3] + rows[2::3]
     img2, hits2 = _render(pkg, med, scene, order)
     assert np.array_equal(img, img2) and np.array_equal(hits, hits2)
+    # the multi-GPU driver's form of the same split: ONE call per rank with shard_index / shard_count
+    import torch
+    rad3 = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    hits3 = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+    for r in range(3):
+        part = scene.copy()
+        part["shard_index"], part["shard_count"] = r, 3
+        med.call("gpis_render_scene_s", part.ctypes.data_as(ctypes.c_void_p), rad3.data_ptr(), hits3.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(img, rad3.cpu().numpy().reshape(H, W)) and np.array_equal(hits, hits3.cpu().numpy().reshape(H, W))
     # checksum of checksums (sum of per-row sums in float64 is order independent here)
     assert float(img.astype(np.float64).sum(axis=1).sum()) == float(img2.astype(np.float64).sum(axis=1).sum())
     # plausible picture: the sphere covers the centre, radiance is bounded by spp * cos <= spp
