@@ -12,9 +12,25 @@
  *
  * Memory convention: every `*_batch` entry takes DEVICE pointers (hipMalloc'd, or a
  * torch tensor's data_ptr) and enqueues on `stream` (a hipStream_t passed as void*,
- * NULL = the null stream) without synchronising.  The `*_host` variants take HOST
- * pointers, stage through an internal device workspace and synchronise before
- * returning — they are what a batch-of-one `Medium` adapter uses.
+ * NULL = the null stream).  The resident-kernel form of the march (the default) never
+ * synchronises; the wavefront form (GPIS_ORDER_SCATTERED with a guide field, or
+ * GPIS_MARCH_FORM_WAVE) synchronises `stream` once per step/sort/evaluate iteration to read
+ * how many rays are left.  The `*_host` variants take HOST pointers, stage through an
+ * internal device workspace and synchronise before returning — they are what a
+ * batch-of-one `Medium` adapter uses.
+ *
+ * Threading: a handle may be used from several host threads on distinct streams, as Tungsten's
+ * render workers use one `const Medium`.  Entry points serialise on a per-handle
+ * mutex while they ENQUEUE (kernels of different callers still overlap on the device); the
+ * workspaces the handle owns (tile drivers, wavefront march) are handed from one caller's stream
+ * to the next with an event, so a second caller never overwrites a workspace still in use.
+ * gpis_destroy / gpis_build_guide / gpis_drop_guide must not race with other calls on the handle.
+ *
+ * Environment: a few diagnostic overrides are read ONCE, in gpis_create, as the initial values
+ * of the options below and of the cell table: GPIS_MARCH=resident|wave, GPIS_WAVE_TAIL=<rays>,
+ * GPIS_PATHS_SORT=0, GPIS_PATHS_PRESORT=0, GPIS_CHUNK_LOG2=<16..28>, GPIS_DISABLE_FAST=1,
+ * GPIS_DISABLE_TABLE=1, GPIS_TABLE_HALF_EXTENT=<cells>, GPIS_PERSIST=0.  Nothing is read from
+ * the environment after gpis_create.  Results never depend on any of them.
  *
  * All functions return GPIS_OK (0) or a negative gpis_status; gpis_last_error()
  * returns a thread-local message for the last failure.
@@ -314,6 +330,20 @@ int gpis_set_profiling(gpis_medium *m, int enable);
  * runs as step / sort / evaluate iterations that regroup the exact evaluations by lattice cell. */
 enum { GPIS_ORDER_COHERENT = 0, GPIS_ORDER_SCATTERED = 1 };
 int gpis_set_batch_order(gpis_medium *m, int order);
+
+/* Tuning options of a handle (speed only — results never depend on them). */
+typedef enum gpis_option {
+    GPIS_OPT_MARCH_FORM = 0,     /* form of the guided march: gpis_march_form; AUTO follows gpis_set_batch_order */
+    GPIS_OPT_WAVE_TAIL = 1,      /* wavefront march: below this many active rays one wave finishes one ray (default 262144; 0 = never) */
+    GPIS_OPT_PATHS_SORT = 2,     /* gpis_render_scene_s_paths: regroup secondary segments by lattice cell (default 1) */
+    GPIS_OPT_PATHS_PRESORT = 3,  /* ... also when the wavefront march (which regroups the exact work itself) runs (default 1) */
+    GPIS_OPT_CHUNK_LOG2 = 4,     /* log2 of the tile drivers' samples per chunk (16..28; 0 = as large as the device holds) */
+    GPIS_OPT_PERSISTENT = 5,     /* per-path media: 1 (default) = persistent refilling march kernels, 0 = one ray per lane per launch */
+    GPIS_OPT_COUNT_
+} gpis_option;
+typedef enum gpis_march_form { GPIS_MARCH_FORM_AUTO = 0, GPIS_MARCH_FORM_RESIDENT = 1, GPIS_MARCH_FORM_WAVE = 2 } gpis_march_form;
+int gpis_set_option(gpis_medium *m, int option, long long value);
+int gpis_get_option(gpis_medium *m, int option, long long *value);
 int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_t *launches,
                             uint64_t *n_eval, uint64_t *n_seg);
 

@@ -221,7 +221,7 @@ class GpisLib:
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
-        "gpis_set_batch_order", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
+        "gpis_set_batch_order", "gpis_set_option", "gpis_get_option", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
         "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
     ]
 
@@ -269,6 +269,8 @@ class GpisLib:
         L.gpis_reset_counters.argtypes = [vp]
         L.gpis_set_profiling.argtypes = [vp, i32]
         L.gpis_get_kernel_profile.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.gpis_set_option.argtypes = [vp, i32, ctypes.c_longlong]
+        L.gpis_get_option.argtypes = [vp, i32, vp]
         L.gpis_build_guide.argtypes = [vp, i32, i32]
         L.gpis_drop_guide.argtypes = [vp]
         L.gpis_get_guide_steps.argtypes = [vp, vp]
@@ -419,6 +421,19 @@ class Medium:
 
     def set_batch_order(self, scattered):
         self.L.check(self.L.lib.gpis_set_batch_order(self.h, 1 if scattered else 0), "gpis_set_batch_order")
+
+    OPTIONS = {"march_form": 0, "wave_tail": 1, "paths_sort": 2, "paths_presort": 3, "chunk_log2": 4, "persistent": 5}
+    MARCH_FORMS = {"auto": 0, "resident": 1, "wave": 2}
+
+    def set_option(self, name, value):
+        if name == "march_form" and isinstance(value, str):
+            value = self.MARCH_FORMS[value]
+        self.L.check(self.L.lib.gpis_set_option(self.h, self.OPTIONS[name], int(value)), "gpis_set_option")
+
+    def get_option(self, name):
+        v = ctypes.c_longlong()
+        self.L.check(self.L.lib.gpis_get_option(self.h, self.OPTIONS[name], ctypes.byref(v)), "gpis_get_option")
+        return v.value
 
     def set_profiling(self, on):
         self.L.check(self.L.lib.gpis_set_profiling(self.h, int(bool(on))), "gpis_set_profiling")

@@ -24,6 +24,10 @@
 //   outside r_i - m >= 1 + 1e-5 : indicator 0 everywhere on C (also for the reference's fp32 test): nothing;
 //   shell   otherwise: at u the reference adds either 0 or w e^{-q(u)}, the interpolant a convex
 //           combination of 0 and w e^{-q(corner)}: they differ by at most sup_C e^{-q} <= exp(-amin max(r_i - m, 0)^2).
+//   position: the march looks the guide up at w = a + t*b (double, GuideRay) while the exact evaluator derives its
+//           position u in fp32; |u - w| <= 1e-4 cells per axis, so inside-class impulses add
+//           1e-4 * sum_a 2 alpha_a (|delta_a(c)| + h/2) exp(-amin max(r_i - m, 0)^2)  (Lipschitz bound of w e^{-q});
+//           the shell and outside classes are already taken over the cell expanded by that slack (mc, hh);
 //   rounding: fp32 accumulation, v_exp_f32, the reference's own fp32 kernel arguments, the lerp: 5e-4
 //           absolute + 1e-3 relative.
 // Impulses farther than 1 + 1e-4 from the block's cells are "outside" for every cell of the block and
@@ -61,6 +65,7 @@ struct GuideField {
 #define GPIS_SOLO_MAX 3
 #endif
 constexpr int kSoloMaxLanes = GPIS_SOLO_MAX;   // clusters up to this size use the sideways evaluator
+constexpr float kGuidePosEps = 1e-4f;         // bound on |u - w| per axis (cells): measured < 2e-5, see GuideRay
 constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the block's cells an impulse contributes exactly 0
 
 // one wave = one 4x4x4 block of grid points
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
     const uint32_t n = M.n_impulses;
     const int H = T.half, S = T.stride;
     const unsigned tside = 2u * (unsigned)H;
-    float Ssum = 0.f, Tsum = 0.f, Esum = 0.f;
+    float Ssum = 0.f, Tsum = 0.f, Esum = 0.f, Lsum = 0.f;
     for (int dx = -2; dx <= 2; ++dx)
         for (int dy = -2; dy <= 2; ++dy)
             for (int dz = -2; dz <= 2; ++dz) {
@@ -135,12 +140,15 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
                         const float cyy = fmaxf(4.f * ay * ay * ady * ady - 2.f * ay, 2.f * ay);
                         const float czz = fmaxf(4.f * az * az * adz * adz - 2.f * az, 2.f * az);
                         Esum += (cxx + cyy + czz) * e_dm;
+                        // Lipschitz term: the exact evaluator's fp32 position u and the lookup position w differ by up to
+                        // kPosEps cells per axis, and |d_a w e^{-q}| = 2 alpha_a |delta_a| e^{-q}
+                        Lsum += 2.f * (ax * adx + ay * ady + az * adz) * e_dm;
                     } else {                                           // the cut-off sphere crosses the cell
                         Tsum += e_dm;
                     }
                 }
             }
-    float err = (h * h * 0.125f) * Esum + Tsum;
+    float err = (h * h * 0.125f) * Esum + Tsum + kGuidePosEps * Lsum;
     err = err * 1.001f + 5e-4f;
     (void)amax;
     F.G[((size_t)ix * F.side + (size_t)iy) * F.side + (size_t)iz] = Ssum;

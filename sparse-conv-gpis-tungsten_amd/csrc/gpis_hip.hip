@@ -105,6 +105,12 @@ struct gpis_medium {
     std::mutex mu;
     // optional per-kernel timing (gpis_set_profiling): event pairs around each march launch
     int batch_hint;          // gpis_set_batch_order: which form of the guided march the *_batch / *_host entries use
+    // tuning options (gpis_set_option; defaults from the GPIS_* environment variables read ONCE in gpis_create)
+    long long opt[GPIS_OPT_COUNT_];
+    // the renderer's workspace (stage[3]) and the wavefront march's (stage[4]) are shared by all callers of this
+    // handle: the last user records an event, the next one makes its stream wait for it
+    hipEvent_t ws_event[2];
+    bool ws_event_set[2];
     bool profiling;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];
     size_t events_used[2];
@@ -1043,6 +1049,23 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     for (int i = 0; i < 5; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
     m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr;
     m->batch_hint = GPIS_ORDER_COHERENT;
+    for (int k = 0; k < 2; ++k) { m->ws_event[k] = nullptr; m->ws_event_set[k] = false; }
+    {   // diagnostic overrides, read here and nowhere else (include/gpis.h: gpis_set_option)
+        m->opt[GPIS_OPT_MARCH_FORM] = GPIS_MARCH_FORM_AUTO;
+        if (const char *e = getenv("GPIS_MARCH")) {
+            if (strcmp(e, "resident") == 0) m->opt[GPIS_OPT_MARCH_FORM] = GPIS_MARCH_FORM_RESIDENT;
+            else if (strcmp(e, "wave") == 0) m->opt[GPIS_OPT_MARCH_FORM] = GPIS_MARCH_FORM_WAVE;
+        }
+        m->opt[GPIS_OPT_WAVE_TAIL] = 262144;
+        if (const char *e = getenv("GPIS_WAVE_TAIL")) m->opt[GPIS_OPT_WAVE_TAIL] = atoll(e) < 0 ? 0 : atoll(e);
+        const char *e1 = getenv("GPIS_PATHS_SORT"), *e2 = getenv("GPIS_PATHS_PRESORT");
+        m->opt[GPIS_OPT_PATHS_SORT] = !(e1 && e1[0] == '0');
+        m->opt[GPIS_OPT_PATHS_PRESORT] = !(e2 && e2[0] == '0');
+        m->opt[GPIS_OPT_PERSISTENT] = 1;
+        if (const char *e = getenv("GPIS_PERSIST")) m->opt[GPIS_OPT_PERSISTENT] = e[0] != '0';
+        m->opt[GPIS_OPT_CHUNK_LOG2] = 0;
+        if (const char *e = getenv("GPIS_CHUNK_LOG2")) { int l = atoi(e); m->opt[GPIS_OPT_CHUNK_LOG2] = l < 16 ? 16 : (l > 28 ? 28 : l); }
+    }
     memset(&m->guide, 0, sizeof m->guide);
     m->profiling = false;
     for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
@@ -1059,13 +1082,14 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         set_err(GPIS_ERR_DEVICE, "gpis_create: %s", hipGetErrorString(e));
         if (m->d_model) (void)hipFree(m->d_model);
         if (m->d_counters) (void)hipFree(m->d_counters);
+        if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
         delete m;
         return GPIS_ERR_DEVICE;
     }
     st = fast_table_build(m->host_model, m->d_model, &m->fast);
     if (st != GPIS_OK) {
         set_err(st, "gpis_create: building the cell table failed");
-        (void)hipFree(m->d_model); (void)hipFree(m->d_counters);
+        (void)hipFree(m->d_model); (void)hipFree(m->d_counters); (void)hipFree(m->d_guide_cnt);
         delete m;
         return st;
     }
@@ -1086,6 +1110,8 @@ extern "C" int gpis_destroy(gpis_medium *m)
         for (auto &ev : m->events[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int i = 0; i < 5; ++i)
         if (m->stage[i]) (void)hipFree(m->stage[i]);
+    for (int k = 0; k < 2; ++k)
+        if (m->ws_event[k]) (void)hipEventDestroy(m->ws_event[k]);
     if (m->d_model) (void)hipFree(m->d_model);
     if (m->d_counters) (void)hipFree(m->d_counters);
     delete m;
@@ -1139,17 +1165,31 @@ struct ProfScope {   // records an event pair around one march-kernel launch whe
 // pixel order: 131 vs 181 ms on C1), the wavefront on scattered rays (1.4x on the second bounce), so the
 // caller's hint decides; GPIS_MARCH=wave|resident overrides it.
 enum MarchHint { MARCH_COHERENT = GPIS_ORDER_COHERENT, MARCH_SCATTERED = GPIS_ORDER_SCATTERED };
-static bool wave_march_selected(int hint)
+static bool wave_march_selected(const gpis_medium *m, int hint)
 {
-    const char *e = getenv("GPIS_MARCH");
-    if (e && strcmp(e, "resident") == 0) return false;
-    if (e && strcmp(e, "wave") == 0) return true;
+    if (m->opt[GPIS_OPT_MARCH_FORM] == GPIS_MARCH_FORM_RESIDENT) return false;
+    if (m->opt[GPIS_OPT_MARCH_FORM] == GPIS_MARCH_FORM_WAVE) return true;
     return hint == MARCH_SCATTERED;
+}
+// shared-workspace hand-over between callers on different streams (slot 0: stage[3], slot 1: stage[4])
+static int ws_acquire(gpis_medium *m, int slot, hipStream_t s)
+{
+    if (m->ws_event_set[slot])
+        HIP_TRY(hipStreamWaitEvent(s, m->ws_event[slot], 0));
+    return GPIS_OK;
+}
+static int ws_release(gpis_medium *m, int slot, hipStream_t s)
+{
+    if (!m->ws_event[slot])
+        HIP_TRY(hipEventCreateWithFlags(&m->ws_event[slot], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->ws_event[slot], s));
+    m->ws_event_set[slot] = true;
+    return GPIS_OK;
 }
 static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const uint8_t *mask, bool want_sample, gpis_seg_out *out,
                       gpis_cond_coeff *coeff, uint8_t *visible, hipStream_t s)
 {
-    if (n > 0xFFFFFFF0ull) return set_err(GPIS_ERR_INVALID_ARG, "wave march: batch too large for 32-bit ray ids");
+    if (n > 0x7FFFFFF0ull) return set_err(GPIS_ERR_INVALID_ARG, "wave march: batch too large (the radix sort takes an int count)");
     size_t temp_bytes = 0;
     if (sort_pairs_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, s) != hipSuccess)
         return set_err(GPIS_ERR_DEVICE, "radix sort scratch query failed");
@@ -1159,6 +1199,7 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
                  o_v1 = carve(n * 4), o_temp = carve(temp_bytes);
     int rc = ensure_stage(m, 4, off);
     if (rc) return rc;
+    if ((rc = ws_acquire(m, 1, s))) return rc;
     char *ws = (char *)m->stage[4];
     unsigned long long *d_req = (unsigned long long *)(ws + o_cnt);
     WaveState *state = (WaveState *)(ws + o_state);
@@ -1173,8 +1214,7 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
         return GPIS_OK;
     };
     HIP_TRY(hipMemsetAsync(d_req, 0, sizeof(unsigned long long), s));
-    size_t tail_limit = 262144;      // measured on the multi-bounce driver: 16 Ki 55.9, 64 Ki 61.5, 256 Ki 65.0, 1 Mi 64.5 M paths/s
-    if (const char *e = getenv("GPIS_WAVE_TAIL")) tail_limit = (size_t)atoll(e);
+    const size_t tail_limit = (size_t)m->opt[GPIS_OPT_WAVE_TAIL];      // default 262144; measured on the multi-bounce driver: 16 Ki 55.9, 64 Ki 61.5, 256 Ki 65.0, 1 Mi 64.5 M paths/s
     size_t n_active = n;
     const uint32_t *active = nullptr;
     int init = 1;
@@ -1225,10 +1265,12 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
             if ((rc = launch_check("k_wave_grad"))) return rc;
         }
         k_wave_finish_sd<<<grid_of(n, 256), 256, 0, s>>>(m->d_model, n, rays, mask, state, out, coeff, cnt);
-        return launch_check("k_wave_finish_sd");
+        if ((rc = launch_check("k_wave_finish_sd"))) return rc;
+        return ws_release(m, 1, s);
     }
     k_wave_finish_tr<<<grid_of(n, 256), 256, 0, s>>>(n, mask, state, visible, cnt);
-    return launch_check("k_wave_finish_tr");
+    if ((rc = launch_check("k_wave_finish_tr"))) return rc;
+    return ws_release(m, 1, s);
 }
 
 static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff,
@@ -1236,7 +1278,7 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
 {
     if (n == 0) return GPIS_OK;
     ProfScope prof(m, 0, s);
-    if (m->guide.enabled && wave_march_selected(hint))
+    if (m->guide.enabled && wave_march_selected(m, hint))
         return wave_march(m, n, rays, mask, true, out, coeff, nullptr, s);
     if (m->guide.enabled) {
         if (m->host_model.exp_arg_max < 100.f)
@@ -1268,7 +1310,7 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
 {
     if (n == 0) return GPIS_OK;
     ProfScope prof(m, 1, s);
-    if (m->guide.enabled && wave_march_selected(hint))
+    if (m->guide.enabled && wave_march_selected(m, hint))
         return wave_march(m, n, rays, mask, false, nullptr, nullptr, visible, s);
     if (m->guide.enabled) {
         if (m->host_model.exp_arg_max < 100.f)
@@ -1298,19 +1340,43 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
 extern "C" int gpis_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && out)));
+    std::lock_guard<std::mutex> lock(m->mu);      // the handle's event lists / wavefront workspace are shared; held while ENQUEUEING only
     HIP_TRY(hipSetDevice(m->device));
     return sample_distance_impl(m, n, rays, out, coeff, nullptr, (hipStream_t)stream, m->batch_hint);
 }
 extern "C" int gpis_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && visible)));
+    std::lock_guard<std::mutex> lock(m->mu);
     HIP_TRY(hipSetDevice(m->device));
     return transmittance_impl(m, n, rays, visible, nullptr, (hipStream_t)stream, m->batch_hint);
 }
 extern "C" int gpis_set_batch_order(gpis_medium *m, int order)
 {
     CHECK_ARGS(m && (order == GPIS_ORDER_COHERENT || order == GPIS_ORDER_SCATTERED));
+    std::lock_guard<std::mutex> lock(m->mu);
     m->batch_hint = order;
+    return GPIS_OK;
+}
+extern "C" int gpis_set_option(gpis_medium *m, int option, long long value)
+{
+    CHECK_ARGS(m && option >= 0 && option < GPIS_OPT_COUNT_);
+    switch (option) {
+    case GPIS_OPT_MARCH_FORM: CHECK_ARGS(value >= GPIS_MARCH_FORM_AUTO && value <= GPIS_MARCH_FORM_WAVE); break;
+    case GPIS_OPT_WAVE_TAIL: CHECK_ARGS(value >= 0); break;
+    case GPIS_OPT_PATHS_SORT: case GPIS_OPT_PATHS_PRESORT: case GPIS_OPT_PERSISTENT: CHECK_ARGS(value == 0 || value == 1); break;
+    case GPIS_OPT_CHUNK_LOG2: CHECK_ARGS(value == 0 || (value >= 16 && value <= 28)); break;
+    default: break;
+    }
+    std::lock_guard<std::mutex> lock(m->mu);
+    m->opt[option] = value;
+    return GPIS_OK;
+}
+extern "C" int gpis_get_option(gpis_medium *m, int option, long long *value)
+{
+    CHECK_ARGS(m && value && option >= 0 && option < GPIS_OPT_COUNT_);
+    std::lock_guard<std::mutex> lock(m->mu);
+    *value = m->opt[option];
     return GPIS_OK;
 }
 extern "C" int gpis_eval_value_batch(gpis_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id, void *stream)
@@ -1652,13 +1718,9 @@ extern "C" void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t h
 // sized for the 288 GB of an MI355X — one launch per stage and frame where it fits — because every launch
 // ends in a tail of half-empty waves and the wavefront march in a tail of thin iterations (C1 frame:
 // 8 Mi-sample chunks 268.8, 32 Mi 284.8, 128 Mi 291.3 Msamples/s; multi-bounce 65 → 80 M paths/s).
-static int chunk_log2(int default_log2)
+static int chunk_log2(const gpis_medium *m, int default_log2)
 {
-    int l = default_log2;
-    if (const char *e = getenv("GPIS_CHUNK_LOG2")) l = atoi(e);
-    if (l < 16) l = 16;
-    if (l > 28) l = 28;
-    return l;
+    return m->opt[GPIS_OPT_CHUNK_LOG2] ? (int)m->opt[GPIS_OPT_CHUNK_LOG2] : default_log2;
 }
 // grows stage[slot] to `bytes` if the device has the memory; false (and no error state) otherwise
 static bool try_stage(gpis_medium *m, int slot, size_t bytes)
@@ -1703,7 +1765,7 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
     size_t chunk_pixels = 0, ns_max = 0, off = 0;
     size_t o_prim = 0, o_seg = 0, o_sh = 0, o_us = 0, o_cos = 0, o_v1 = 0, o_v2 = 0, o_vis = 0, o_hit = 0;
     int rc = GPIS_OK;
-    for (int l = chunk_log2(27);; --l) {
+    for (int l = chunk_log2(m, 27);; --l) {
         chunk_pixels = ((size_t)1 << l) / s->spp_count;
         if (chunk_pixels < 1) chunk_pixels = 1;
         if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
@@ -1716,6 +1778,7 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
             break;
         if (l <= 20) return set_err(GPIS_ERR_DEVICE, "scene driver: no memory for a 1 Mi-sample workspace");
     }
+    if ((rc = ws_acquire(m, 0, st))) return rc;
     char *ws = (char *)m->stage[3];
     gpis_ray_in *prim = (gpis_ray_in *)(ws + o_prim);
     gpis_seg_out *seg = (gpis_seg_out *)(ws + o_seg);
@@ -1734,7 +1797,7 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
         k_scene_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, p0, np, cosl, v2, vis, hit, radiance_sum, hit_count);
         if ((rc = launch_check("k_scene_accumulate"))) return rc;
     }
-    return GPIS_OK;
+    return ws_release(m, 0, st);
 }
 
 extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, int max_path_bounces, float albedo, float *radiance_sum, void *stream)
@@ -1746,7 +1809,7 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
     hipStream_t st = (hipStream_t)stream;
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = scene_rows(*s) * s->width;
-    size_t chunk_pixels = ((size_t)1 << chunk_log2(25)) / s->spp_count;
+    size_t chunk_pixels = ((size_t)1 << chunk_log2(m, 25)) / s->spp_count;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
     const size_t ns_max = chunk_pixels * s->spp_count;
@@ -1756,10 +1819,8 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
     size_t o_rng = carve(ns_max * 8), o_thr = carve(ns_max * 4), o_em = carve(ns_max * 4), o_con = carve(ns_max * 4);
     size_t o_alive = carve(ns_max), o_nee = carve(ns_max), o_vis = carve(ns_max);
     // regrouping of secondary segments (GPIS_PATHS_SORT=0 keeps the sample order: results are identical)
-    const char *sort_env = getenv("GPIS_PATHS_SORT");
-    const bool regroup = !(sort_env && sort_env[0] == '0') && max_path_bounces > 2;
-    const char *presort_env = getenv("GPIS_PATHS_PRESORT");
-    const bool presort = !(presort_env && presort_env[0] == '0');
+    const bool regroup = m->opt[GPIS_OPT_PATHS_SORT] != 0 && max_path_bounces > 2;
+    const bool presort = m->opt[GPIS_OPT_PATHS_PRESORT] != 0;
     size_t sort_temp_bytes = 0;
     size_t o_keys = 0, o_vals = 0, o_keys2 = 0, o_order = 0, o_rsorted = 0, o_live = 0, o_temp = 0, o_order2 = 0, o_live2 = 0;
     if (regroup) {
@@ -1771,6 +1832,7 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
     }
     int rc = ensure_stage(m, 3, off);
     if (rc) return rc;
+    if ((rc = ws_acquire(m, 0, st))) return rc;
     char *ws = (char *)m->stage[3];
     uint32_t *keys = (uint32_t *)(ws + o_keys), *vals = (uint32_t *)(ws + o_vals), *keys2 = (uint32_t *)(ws + o_keys2), *order = (uint32_t *)(ws + o_order);
     gpis_ray_in *rays_sorted = (gpis_ray_in *)(ws + o_rsorted);
@@ -1796,7 +1858,7 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
             // GPIS_PATHS_PRESORT=0 skips it when the wavefront march runs, which regroups the exact work
             // itself).  Measured at 4 bounces, C1 1080p x16: sample order + resident march 22.1 M paths/s,
             // regrouped + resident 40.4, wavefront march alone 56.7, regrouped + wavefront 61.3.
-            const bool wave = bounce > 0 && m->guide.enabled && wave_march_selected(MARCH_SCATTERED);
+            const bool wave = bounce > 0 && m->guide.enabled && wave_march_selected(m, MARCH_SCATTERED);
             const bool sorted = regroup && bounce > 0 && (!wave || presort);
             const int hint = bounce > 0 ? MARCH_SCATTERED : MARCH_COHERENT;
             // src rays + mask -> order, regrouped copy, live flags of the regrouped slots
@@ -1832,7 +1894,7 @@ extern "C" int gpis_render_scene_s_paths(gpis_medium *m, const gpis_scene_s *s, 
         k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, p0, np, a.emission, radiance_sum);
         if ((rc = launch_check("k_paths_accumulate"))) return rc;
     }
-    return GPIS_OK;
+    return ws_release(m, 0, st);
 }
 
 extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, const gpis_surface_s *surf, float *radiance_sum, void *stream)
@@ -1845,7 +1907,7 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
     hipStream_t st = (hipStream_t)stream;
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = scene_rows(*s) * s->width;
-    size_t chunk_pixels = ((size_t)1 << chunk_log2(24)) / s->spp_count;
+    size_t chunk_pixels = ((size_t)1 << chunk_log2(m, 24)) / s->spp_count;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
     const size_t ns_max = chunk_pixels * s->spp_count;
@@ -1862,6 +1924,7 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
     for (int k = 0; k < 7; ++k) o_f[k] = carve(ns_max);
     int rc = ensure_stage(m, 3, off);
     if (rc) return rc;
+    if ((rc = ws_acquire(m, 0, st))) return rc;
     char *ws = (char *)m->stage[3];
     a.rays = (gpis_ray_in *)(ws + o_rays); a.seg = (gpis_seg_out *)(ws + o_seg); a.shadow = nullptr;
     a.rng = (uint64_t *)(ws + o_rng); a.throughput = (float *)(ws + o_thr); a.emission = (float *)(ws + o_em); a.contrib = nullptr;
@@ -1893,5 +1956,5 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
         k_paths_accumulate<<<grid_of(np, 256), 256, 0, st>>>(sc, p0, np, a.emission, radiance_sum);
         if ((rc = launch_check("k_paths_accumulate"))) return rc;
     }
-    return GPIS_OK;
+    return ws_release(m, 0, st);
 }

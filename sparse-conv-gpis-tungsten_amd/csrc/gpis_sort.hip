@@ -13,6 +13,8 @@ namespace gpis {
 hipError_t sort_pairs_u32(void *temp, size_t &temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *vals_in, uint32_t *vals_out, size_t n, hipStream_t stream)
 {
+    if (n > (size_t)0x7FFFFFFF)
+        return hipErrorInvalidValue;      // the library's count is an int
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 32, stream);
 }
 

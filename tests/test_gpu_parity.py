@@ -104,12 +104,6 @@ def _medium(pkg, params, path):
                        every batch; test batches are small, so the one-wave-per-ray tail does most of it
       guided_wave_tail0  the same with the tail kernel disabled: every value goes through step/sort/eval"""
     import os
-    os.environ.pop("GPIS_MARCH", None)
-    os.environ.pop("GPIS_WAVE_TAIL", None)
-    if path.startswith("guided_wave"):
-        os.environ["GPIS_MARCH"] = "wave"          # read at every call: stays set until the next _medium()
-        if path.endswith("tail0"):
-            os.environ["GPIS_WAVE_TAIL"] = "0"
     env = {"generic": {"GPIS_DISABLE_FAST": "1"}, "fast_gen": {"GPIS_DISABLE_TABLE": "1"},
            "fast_small_table": {"GPIS_TABLE_HALF_EXTENT": "4"}, "fast": {}}.get(path, {})
     keys = ("GPIS_DISABLE_FAST", "GPIS_DISABLE_TABLE", "GPIS_TABLE_HALF_EXTENT")
@@ -122,6 +116,10 @@ def _medium(pkg, params, path):
         for k in keys:
             os.environ.pop(k, None)
     assert int(med.derived()["fast_path"]) == (0 if path == "generic" else 1)
+    if path.startswith("guided_wave"):
+        med.set_option("march_form", "wave")
+        if path.endswith("tail0"):
+            med.set_option("wave_tail", 0)
     if path == "guided_coarse" or path.startswith("guided_wave"):
         med.build_guide(16, 8)
     elif path == "guided_fine_partial":
@@ -487,14 +485,11 @@ def test_render_scene_s_paths(env, path):
         got = rad.cpu().numpy().reshape(h, w)
         assert np.array_equal(got, want), (cfg, np.abs(got - want).max())
         # the regrouping of secondary segments (lattice-space sort + compaction) changes no result
-        import os
-        os.environ["GPIS_PATHS_SORT"] = "0"
-        try:
-            rad.zero_()
-            med.call("gpis_render_scene_s_paths", sc.ctypes.data_as(ctypes.c_void_p), bounces, 0.8, rad.data_ptr(), stream_ptr())
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["GPIS_PATHS_SORT"]
+        assert med.get_option("paths_sort") == 1
+        med.set_option("paths_sort", 0)
+        rad.zero_()
+        med.call("gpis_render_scene_s_paths", sc.ctypes.data_as(ctypes.c_void_p), bounces, 0.8, rad.data_ptr(), stream_ptr())
+        torch.cuda.synchronize()
         assert np.array_equal(rad.cpu().numpy().reshape(h, w), want), cfg
         # more bounces only add light
         assert (want >= single).all() and want.sum() > single.sum() > 0
