@@ -276,8 +276,8 @@ bool HipSparseConvNoiseMedium::sampleDistance(PathSampleGenerator &sampler, cons
         sample.sparseConv1DSamplingScheme = SparseConv1DSamplingScheme::UNI;
         return true;
     }
-    if (_absorptionOnly && ray.farT() == Ray::infinity())
-        return false;
+    // (GaussianProcessMedium.cpp:251-252 tests maxT against infinity AFTER the clamp above: dead code in the
+    //  reference, so an infinite absorbing segment is marched over its 2000 units there and here)
 
     gpis_ray_in r;
     gpis_seg_out o;

@@ -323,8 +323,10 @@ void HipSparseConvNoiseMedium::applyResult(const Ray &ray, const gpis_seg_out &o
     sample.p.x = o.p[0]; sample.p.y = o.p[1]; sample.p.z = o.p[2];
     sample.sparseConv1DSamplingScheme = (SparseConv1DSamplingScheme)o.scheme;
     const bool absorption = _sigmaS[0] == 0.f && _sigmaS[1] == 0.f && _sigmaS[2] == 0.f;
-    if (!absorption)                           // the absorption-only branch (GPM.cpp:250-258) does not advance
+    if (!absorption)                           // the absorption-only branch (GPM.cpp:250-258) does not advance;
         state.advance();
+    else if (o.weight[0] == 0.f)               // its transmittance() clears firstScatter on a hit only (GPM.cpp:371-381)
+        state.firstScatter = false;
     sample.phase = state.lastGPId;             // index into _phaseFunctions (GPM.cpp:335)
     sample.gpId = state.lastGPId;
     sample.ctxt = state.gpContext.get();

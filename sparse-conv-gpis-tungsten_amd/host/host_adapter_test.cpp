@@ -156,6 +156,34 @@ static void test_gpu()
     MediumState st0;
     CHECK(m.sampleDistance(s3, Ray(o, rays[0].dir, 0.f, 0.f), st0, smp) && smp.exited && smp.t == 0.f && st0.bounce == 0 && st0.firstScatter);
     m.teardownAfterRender();
+
+    // absorption-only medium (sigma_s = 0: the reference's default when the key is missing, GPM.cpp:87-88):
+    // sampleDistance returns weight = transmittance and does NOT advance the state (GPM.cpp:250-258)
+    HipSparseConvNoiseMedium a;
+    std::string js = kSceneC1;
+    js.replace(js.find("\"sigma_a\": 0, \"sigma_s\": 1"), std::strlen("\"sigma_a\": 0, \"sigma_s\": 1"), "\"sigma_a\": 1, \"sigma_s\": 0");
+    a.fromJson(js);
+    a.prepareForRender(0);
+    int blocked = 0, clear = 0;
+    for (int i = 0; i < 48; ++i) {
+        MediumState sa;
+        sa.reset();
+        sa.info.pixelSampleSegment[0] = 7 + i; sa.info.sceneSeed = 0xBA5EBA11u;
+        Vec3f d; d.x = -0.4f + 0.017f * i; d.y = 0.01f; d.z = -1.f;
+        float len = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+        d.x /= len; d.y /= len; d.z /= len;
+        ConstSampler sm(0.3f);
+        MediumSample out;
+        bool ok = a.sampleDistance(sm, Ray(o, d, 2.4f, 5.6f), sa, out);
+        CHECK(ok && out.exited && out.t == 5.6f && sm.calls == 1);
+        CHECK(sa.bounce == 0);                                     // no advance()
+        CHECK(out.weight.x == 0.f || out.weight.x == 1.f);
+        CHECK(sa.firstScatter == (out.weight.x == 1.f));           // cleared by the hit inside transmittance() only
+        CHECK(sa.info.t == 5.6f && out.rayInfo.t == 5.6f);
+        (out.weight.x == 0.f ? blocked : clear)++;
+    }
+    CHECK(blocked > 5 && clear > 5);
+    a.teardownAfterRender();
 }
 
 int main(int argc, char **argv)

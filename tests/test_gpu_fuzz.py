@@ -53,6 +53,13 @@ def _random_params(pkg, rng):
         p["mean_additional"]["type"] = pkg.MEAN_TYPE.SPHERICAL
         p["mean_additional"]["center"] = rng.uniform(-0.8, 0.8, 3)
         p["mean_additional"]["radius"] = float(rng.uniform(0.3, 0.7))
+    # medium coefficients (GPM.cpp:152-158): sigma_s = 0 is the reference's default and selects the absorption-only
+    # branch of sampleDistance (GPM.cpp:250-258)
+    p["density"] = float(rng.choice([0.5, 1.0, 2.0]))
+    p["sigma_a"] = rng.choice([0.0, 0.25, 1.0], 3).astype(f32)
+    p["sigma_s"] = (np.zeros(3) if rng.random() < 0.25 else rng.choice([0.5, 1.0, 3.0], 3)).astype(f32)
+    p["surf_vol_phase_separate"] = int(rng.random() < 0.25)
+    p["surf_vol_phase_amp_thresh"] = float(rng.choice([0.0, 0.5, 2.0]))
     if rng.random() < 0.3:
         p["nonstationary"] = 1
         p["multi_resolution_grid"] = int(rng.integers(0, 2))
@@ -133,7 +140,8 @@ def test_random_configuration(pkg, ob, seed):
     want, cw = orc.sample_distance(rays, want_coeff=True)
     vis_g, vis_o = med.transmittance(rays), orc.transmittance(rays)
     desc = {k: (params[k].tolist() if hasattr(params[k], "tolist") else params[k]) for k in
-            ("single_realization", "isotropic_3d_sampling", "sampling_1d", "correlation_context", "nonstationary", "multi_resolution_grid", "use_aniso_mtx", "has_mean_additional")}
+            ("single_realization", "isotropic_3d_sampling", "sampling_1d", "correlation_context", "nonstationary", "multi_resolution_grid", "use_aniso_mtx", "has_mean_additional",
+             "sigma_s", "surf_vol_phase_separate")}
     print("seed", seed, desc, "mean", int(params["mean"]["type"]), "fast", int(d_g["fast_path"]), "hits", int((want["exited"] == 0).sum()),
           "blocked", int((vis_o == 0).sum()))
     if exact:

@@ -183,6 +183,47 @@ def test_march_edge_cases(env, path):
     assert med.sample_distance(rays[:0]).shape == (0,)
 
 
+@pytest.mark.parametrize("cfg", ["C0", "C1", "C2", "C0_perpath"])
+def test_absorption_only_branch(env, cfg):
+    """sigma_s = 0 (the reference's default when the JSON omits the key, GPM.cpp:87-88): sampleDistance takes the
+    absorption-only branch (GPM.cpp:250-258) — weight = transmittance, exited, no state.advance()."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C0" if cfg == "C0_perpath" else cfg)
+    if cfg == "C0_perpath":
+        params["single_realization"] = 0
+        params["correlation_context"] = pkg.CTX.RENEWAL_PLUS
+    params["sigma_s"] = 0.0
+    params["sigma_a"] = (0.5, 1.0, 2.0)
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    assert int(med.derived()["fast_path"]) == 0          # the cooperative kernels do not cover this branch
+    scene = ob.default_scene_s(128, 128, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    rays = rays.copy()
+    rays["far_t"][:2] = (np.inf, 0.0)                    # infinite far -> returns false (GPM.cpp:251-252); maxT == 0 shortcut
+    rays["near_t"][1] = 0.0
+    # second segments too (conditioning live for the per-path medium): start them from a scattering twin's hits
+    p2 = params.copy()
+    p2["sigma_s"] = 1.0
+    first = ob.Oracle(p2, threads=16).sample_distance(rays)
+    sh = shadow_rays_from(ob, scene, rays, us, first)
+    batch = np.concatenate([rays, sh])
+    got, cg = med.sample_distance(batch, want_coeff=True)
+    want, cw = orc.sample_distance(batch, want_coeff=True)
+    exact = not int(params["sampling_1d"])
+    for f in got.dtype.names:
+        if exact or f not in ("aniso",):
+            assert np.array_equal(got[f], want[f], equal_nan=True), f
+        else:
+            assert _close(got[f], want[f]), f
+    for f in ("value_scale", "gradient_scale", "ray_origin", "n_evals"):
+        if exact or f in ("ray_origin", "n_evals"):
+            assert np.array_equal(cg[f], cw[f]), f
+    assert (want["ok"] == 1).sum() > 100 and (want["exited"] == 1).all()
+    w = want["weight"][want["ok"] == 1][:, 0]
+    assert (w == 0).sum() > 20 and (w == 1).sum() > 20    # blocked and unblocked segments
+    assert np.array_equal(med.transmittance(batch), orc.transmittance(batch))
+
+
 @pytest.mark.parametrize("ctx", ["RENEWAL", "RENEWAL_PLUS", "NONE", "GLOBAL"])
 @pytest.mark.parametrize("iso", [0, 1])
 def test_per_path_realizations_and_conditioning(env, ctx, iso):

@@ -1,0 +1,114 @@
+"""Independent evidence for the oracle's float chain where no reference-produced vector exists
+(DESIGN.md §3): the PUBLISHED property of the construction.  Sparse-convolution noise with the
+squared-exponential splatting kernel, normalised by sqrt(sparseConvNoiseVariance) (GPF.cpp:741-760),
+is a unit-variance field whose two-point covariance is the SE kernel:
+
+    Var[(f(p) - mean(p)) / sigma] = 1,      Cov[...] (p, p + d) = exp(-|d|^2 / (2 l^2))
+
+(l = "lengthScale" in world units; with "aniso" a the distance is measured in p/a).  A wrong
+normalisation constant, a wrong l_conv = l*sqrt(2)/2 (GPF.cpp:654-679), a wrong kernel matrix
+(GPF.cpp:774-802), or impulses drawn from the wrong cells all show up here.  Realisations are
+independent across paths when single_realization = false (computeSeed, SCN.cpp:40-49), so ONE batch
+of queries with distinct pixel words samples the ensemble.  Checked in the three sampling spaces:
+world, isotropic-ray (the headline config's space) and 1D along the ray."""
+import numpy as np
+import pytest
+
+N = 40000          # realisations per estimate: standard error of a correlation estimate <= 1/sqrt(N) = 0.005
+TOL = 0.03         # 6 standard errors (the field is close to, not exactly, Gaussian: rho impulses per cell)
+
+
+def _ensemble(pkg, orc, pts, direction):
+    """value at every point of `pts` for N independent realisations: array (len(pts), N) of (f - mean)/sigma"""
+    out = []
+    for p in pts:
+        q = np.zeros(N, dtype=pkg.QUERY)
+        q["p"] = np.asarray(p, dtype=np.float32)
+        q["dir"] = np.asarray(direction, dtype=np.float32)
+        q["pixel"][:, 0] = np.arange(N) % 4096          # the path identity = the realisation (SCN.cpp:40-49)
+        q["pixel"][:, 1] = np.arange(N) // 4096
+        q["spp"] = 3
+        q["segment"] = 0
+        q["scene_seed"] = 0xBA5EBA11
+        v, _ = orc.eval_value(q)
+        out.append(v.astype(np.float64))
+    return np.array(out)
+
+
+def _params(pkg, space, rho, aniso=(1, 1, 1)):
+    p = pkg.params_for_config("C0")
+    p["single_realization"] = 0
+    p["correlation_context"] = pkg.CTX.NONE
+    p["impulse_density"] = rho
+    p["aniso"] = aniso
+    p["mean"]["type"] = pkg.MEAN_TYPE.HOMOGENEOUS      # mean = offset: subtracting it is exact
+    p["mean"]["offset"] = 0.25
+    if space == "iso_ray":
+        p["isotropic_3d_sampling"] = 1
+    elif space == "1d":
+        p["isotropic_3d_sampling"] = 1
+        p["sampling_1d"] = 1
+    return p
+
+
+@pytest.mark.parametrize("space,rho", [("world", 8), ("world", 32), ("iso_ray", 32), ("1d", 32)])
+def test_unit_variance_and_se_covariance(pkg, ob, space, rho):
+    params = _params(pkg, space, rho)
+    orc = ob.Oracle(params, threads=8)
+    sigma, l = float(params["sigma"]), float(params["length_scale"])
+    d = np.array([0.0, 0.0, 1.0])                        # ray direction; 1D noise only varies along it
+    base = np.array([0.31, -0.17, 0.23])
+    seps = [0.0, 0.5 * l, 1.0 * l, 2.0 * l]
+    pts = [base + s * d for s in seps]
+    if space != "1d":                                     # 3D fields: also an off-axis separation
+        pts.append(base + 1.0 * l * np.array([0.6, 0.8, 0.0]))
+        seps.append(1.0 * l)
+    vals = (_ensemble(pkg, orc, pts, d) - 0.25) / sigma
+    assert abs(vals.mean()) < TOL
+    var = vals.var(axis=1)
+    assert np.all(np.abs(var - 1.0) < 2 * TOL), var       # variance estimates carry kurtosis: twice the tolerance
+    for k in range(1, len(pts)):
+        corr = float(np.mean(vals[0] * vals[k]) / np.sqrt(var[0] * var[k]))
+        want = float(np.exp(-seps[k] ** 2 / (2 * l * l)))
+        assert abs(corr - want) < TOL, (space, rho, seps[k] / l, corr, want)
+
+
+def test_anisotropic_kernel_covariance(pkg, ob):
+    """aniso = (a_x, a_y, a_z) stretches the length scale per axis (GPF.cpp:659-666): the covariance along axis k at
+    separation s is exp(-s^2 / (2 (l a_k)^2)) — in world space and, through the whitening transform, in
+    isotropic-ray space."""
+    aniso = (1.0, 2.0, 0.5)
+    for space in ("world", "iso_ray"):
+        params = _params(pkg, space, 16, aniso)
+        orc = ob.Oracle(params, threads=8)
+        sigma, l = float(params["sigma"]), float(params["length_scale"])
+        base = np.array([0.11, 0.42, -0.3])
+        s = 0.8 * l
+        pts = [base] + [base + s * np.eye(3)[k] for k in range(3)]
+        vals = (_ensemble(pkg, orc, pts, (0.0, 0.6, 0.8)) - 0.25) / sigma
+        var = vals.var(axis=1)
+        assert np.all(np.abs(var - 1.0) < 2 * TOL), (space, var)
+        for k in range(3):
+            corr = float(np.mean(vals[0] * vals[k + 1]) / np.sqrt(var[0] * var[k + 1]))
+            want = float(np.exp(-s ** 2 / (2 * (l * aniso[k]) ** 2)))
+            assert abs(corr - want) < TOL, (space, k, corr, want)
+
+
+def test_gradient_variance(pkg, ob):
+    """The derivative of an SE field has variance sigma^2 / l^2 per axis: pins the gradient chain
+    (splattingKernel3D's gradient part, GPF.cpp:804-817, and the l2w transform of SCN.cpp:305)."""
+    for space in ("world", "iso_ray"):
+        params = _params(pkg, space, 16)
+        orc = ob.Oracle(params, threads=8)
+        sigma, l = float(params["sigma"]), float(params["length_scale"])
+        q = np.zeros(N, dtype=pkg.QUERY)
+        q["p"] = (0.2, -0.4, 0.1)
+        q["dir"] = (0.0, 0.6, 0.8)
+        q["pixel"][:, 0] = np.arange(N) % 4096
+        q["pixel"][:, 1] = np.arange(N) // 4096
+        q["scene_seed"] = 0xBA5EBA11
+        g = orc.eval_gradient(q).astype(np.float64)
+        var = g.var(axis=0) / (sigma / l) ** 2
+        assert np.all(np.abs(var - 1.0) < 3 * TOL), (space, var)
+        c = np.corrcoef(g.T)
+        assert abs(c[0, 1]) < TOL and abs(c[0, 2]) < TOL and abs(c[1, 2]) < TOL
