@@ -29,7 +29,7 @@
  * Environment: a few diagnostic overrides are read ONCE, in gpis_create, as the initial values
  * of the options below and of the cell table: GPIS_MARCH=resident|wave, GPIS_WAVE_TAIL=<rays>,
  * GPIS_PATHS_SORT=0, GPIS_PATHS_PRESORT=0, GPIS_CHUNK_LOG2=<16..28>, GPIS_DISABLE_FAST=1,
- * GPIS_DISABLE_TABLE=1, GPIS_TABLE_HALF_EXTENT=<cells>, GPIS_PERSIST=0.  Nothing is read from
+ * GPIS_DISABLE_TABLE=1, GPIS_TABLE_HALF_EXTENT=<cells>, GPIS_PERSIST=0, GPIS_SOLO_MAX=<lanes>.  Nothing is read from
  * the environment after gpis_create.  Results never depend on any of them.
  *
  * All functions return GPIS_OK (0) or a negative gpis_status; gpis_last_error()
@@ -339,6 +339,8 @@ typedef enum gpis_option {
     GPIS_OPT_PATHS_PRESORT = 3,  /* ... also when the wavefront march (which regroups the exact work itself) runs (default 1) */
     GPIS_OPT_CHUNK_LOG2 = 4,     /* log2 of the tile drivers' samples per chunk (16..28; 0 = as large as the device holds) */
     GPIS_OPT_PERSISTENT = 5,     /* per-path media: 1 (default) = persistent refilling march kernels, 0 = one ray per lane per launch */
+    GPIS_OPT_SOLO_MAX = 6,       // persistent march: evaluate sideways (lane = impulse) while at most this many lanes of a wave have a
+                                 //   pending evaluation; -1 (default) = derived from impulse_density
     GPIS_OPT_COUNT_
 } gpis_option;
 typedef enum gpis_march_form { GPIS_MARCH_FORM_AUTO = 0, GPIS_MARCH_FORM_RESIDENT = 1, GPIS_MARCH_FORM_WAVE = 2 } gpis_march_form;

@@ -1330,6 +1330,7 @@ static void state_from_ray(const gpis_ray_in *r, medium_state *s)
 }
 
 static int transmittance_one(const oracle_medium *m, oracle_counters *cnt, const gpis_ray_in *ray, medium_state *state);
+static int transmittance_with(realization *noise_io, const gpis_ray_in *ray, medium_state *state);
 
 /* GaussianProcessMedium::sampleDistance, GPM.cpp:221-341 */
 static void sample_distance_one(const oracle_medium *m, oracle_counters *cnt, const gpis_ray_in *ray, gpis_seg_out *out, gpis_cond_coeff *coeff)
@@ -1372,7 +1373,7 @@ static void sample_distance_one(const oracle_medium *m, oracle_counters *cnt, co
         if (maxT == INFINITY) { out->ok = 0; return; }
         out->sample_t = maxT;
         medium_state st2 = state;
-        int vis = transmittance_one(m, cnt, ray, &st2);
+        int vis = transmittance_with(&noise, ray, &st2);
         state = st2; /* transmittance mutates the caller's state (GPM.cpp:254 passes &state) */
         out->weight[0] = out->weight[1] = out->weight[2] = vis ? 1.f : 0.f;
         out->exited = 1;
@@ -1454,11 +1455,20 @@ done:
 }
 
 /* GaussianProcessMedium::transmittance, GPM.cpp:343-393 → 1 if the segment exits */
+static int transmittance_with(realization *noise_io, const gpis_ray_in *ray, medium_state *state);
 static int transmittance_one(const oracle_medium *m, oracle_counters *cnt, const gpis_ray_in *ray, medium_state *state)
 {
     realization noise;
     memset(&noise, 0, sizeof noise);
     noise.m = m; noise.cnt = cnt;
+    return transmittance_with(&noise, ray, state);
+}
+/* the same with the caller's realization: intersectGP leaves the realization it marched with in state.gpContext
+ * (SCNM.cpp:165-167, 178-180), which is what MediumSample.ctxt points to after the absorption-only branch of
+ * sampleDistance (GPM.cpp:254, 337) */
+static int transmittance_with(realization *noise_io, const gpis_ray_in *ray, medium_state *state)
+{
+#define noise (*noise_io)
     v3f pos = v3(ray->pos[0], ray->pos[1], ray->pos[2]);
     v3f dir = v3(ray->dir[0], ray->dir[1], ray->dir[2]);
     double startT = ray->near_t;
@@ -1486,6 +1496,7 @@ static int transmittance_one(const oracle_medium *m, oracle_counters *cnt, const
         startT = t;
     } while (t < maxT && exited);
     return exited ? 1 : 0;
+#undef noise
 }
 
 /* ======================================================================================

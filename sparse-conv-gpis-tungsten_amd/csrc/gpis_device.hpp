@@ -318,6 +318,132 @@ GPIS_DEV void mean_weight_space(const DevModel &M, V3d p, double &mean, int &id)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// wave-level primitives shared by the cooperative kernels (gpis_fast.hpp, gpis_guide.hpp) and the persistent
+// march (gpis_persist.inc)
+// ---------------------------------------------------------------------------------------
+// ---- LCG jump-ahead tables: state after n further draws = A_n * s + C_n -------------------
+struct JumpTable {
+    uint64_t A[64];
+    uint64_t C[64];
+};
+constexpr JumpTable make_jump_table()
+{
+    JumpTable t{};
+    uint64_t a = 1, c = 0;
+    for (int n = 0; n < 256; ++n) {
+        if ((n & 3) == 0) { t.A[n >> 2] = a; t.C[n >> 2] = c; }
+        a = a * kPcgMult;
+        c = c * kPcgMult + 1ULL;
+    }
+    return t;
+}
+__device__ const JumpTable kJump4 = make_jump_table();   // entry k: jump by 4k draws
+
+// one wave per cell: lane k produces impulse k exactly as the sequential generator (SCN.cpp:376-385)
+GPIS_DEV void gen_impulse(uint32_t ci, uint32_t cj, uint32_t ck, uint32_t seed, uint64_t jA, uint64_t jC,
+                          float &px, float &py, float &pz, float &pw)
+{
+    const uint32_t h = xxhash32_4(ck, cj, ci, seed) + 1u;
+    const uint64_t s0 = (uint64_t)h * (kPcgMult * kPcgMult) + (kPcgMult + 1ULL);   // set_state
+    Pcg32 g;
+    g.state = jA * s0 + jC;
+    pz = normalized_uint(g.next_i());
+    py = normalized_uint(g.next_i());
+    px = normalized_uint(g.next_i());
+    pw = (g.next_i() >> 31) ? 1.f : -1.f;   // Bernoulli(next1D(), -1, 1, 0.5)
+}
+typedef float float2v __attribute__((ext_vector_type(2)));    // two fp32 lanes of a v_pk_* instruction
+#ifndef GPIS_LDS_BCAST
+#define GPIS_LDS_BCAST 1                // 1: candidate impulses are broadcast through LDS, 0: with v_readlane
+#endif
+struct FastLds {
+    uint64_t exptab[32];                // glibc's exp2f table, staged once per wave (ds_read_b64 per use)
+#if GPIS_LDS_BCAST
+    // the current cell's impulses, read back at a wave-uniform address (= broadcast), laid out in the
+    // pairs the candidate body consumes with packed fp32 instructions
+    float4 xyr[64];                     // (x, y, kernelRadius * x, kernelRadius * y)
+    float4 zw[64];                      // (z, kernelRadius * z, w = +-1, unused)
+#endif
+};
+template <class LDS>
+GPIS_DEV void fast_lds_init(LDS &lds)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    if (lane < 32)
+        lds.exptab[lane] = kExp2fTab[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// wave-uniform value → SGPR
+GPIS_DEV int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+GPIS_DEV float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// lane k's value, k wave-uniform (v_readlane_b32: no LDS round trip)
+GPIS_DEV float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
+// expf_glibc with the table in LDS and the range checks folded into selects (same results).
+// NONPOS: the caller guarantees x <= 0 (or NaN), so the overflow check cannot fire and is left out.
+// NOUNDER: the caller guarantees that every result it USES has x >= -100 (results of smaller x are
+// discarded), so the underflow select is left out as well.
+// (LDS = any struct with the staged table as `uint64_t exptab[32]`)
+template <bool NONPOS = false, bool NOUNDER = false, class LDS = FastLds>
+GPIS_DEV float expf_glibc_lds(const LDS &lds, float x)
+{
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32;
+    const double Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    double z = InvLn2N * (double)x;
+    double kd = z + Shift;
+    uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    uint64_t t = lds.exptab[ki & 31];
+    kd -= Shift;
+    double r = z - kd;
+    t += ki << (52 - 5);
+    double zz = __builtin_fma(C0, r, C1);
+    double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(zz, r2, y);
+    y = y * __longlong_as_double((long long)t);
+    float res = (float)y;
+    if (!NOUNDER)
+        res = x < -0x1.9fe368p6f ? 0.0f : res;
+    if (!NONPOS)
+        res = x > 0x1.62e42ep6f ? __builtin_huge_valf() : res;
+    return res;
+}
+
+
+// ---- persistent march (gpis_persist.inc) ------------------------------------------------------------------
+template <int Q>
+struct PersistQueue {
+    uint64_t exptab[32];                           // glibc's exp2f table (expf_glibc_lds)
+    uint32_t e0[Q][64], e1[Q][64], e2[Q][64];      // (x | w sign, y, z) of the impulses that passed the unit-ball test, slot-major
+};
+enum PersistPhase : int {
+    PP_IDLE = 0,      // no ray (batch drained)
+    PP_COND = 1,      // unconditioned evaluation at the segment start (conditioning, SCN.cpp:431-595)
+    PP_F0 = 2,        // f(nearT)                                   SCNM.cpp:125-128
+    PP_MARCH = 3,     // f(t), fixed steps                           SCNM.cpp:132-141, 172-173
+    PP_REFINE = 4,    // secant-then-shrink refinement               SCNM.cpp:142-162
+    PP_FINAL = 5,     // lastVal = f(farT) on exit                   SCNM.cpp:176-181
+    PP_GRAD = 6,      // sampleGradient                              SCNM.cpp:93-100, GPM.cpp:283 / 319
+    PP_DONE = 7       // result complete: write it, take the next ray
+};
+struct PersistArgs {
+    size_t n;
+    const gpis_ray_in *rays;
+    gpis_seg_out *out;            // sampleDistance
+    gpis_cond_coeff *coeff;       // sampleDistance, optional
+    uint8_t *visible;             // transmittance
+    const uint8_t *mask;          // optional
+    Counters *cnt;
+    unsigned int *next;           // the global ray counter of this launch (zeroed by the host)
+    int solo_max;                 // sideways evaluation when at most this many lanes have a job
+};
+
 // ---- plain data shared by every specialisation of the path section ------------------------
 struct LevelInfo { float lo, hi, ratio_lo, ratio_hi; int add_lo, add_hi; };
 struct NeeShared {

@@ -31,24 +31,6 @@
 
 namespace gpis {
 
-// ---- LCG jump-ahead tables: state after n further draws = A_n * s + C_n -------------------
-struct JumpTable {
-    uint64_t A[64];
-    uint64_t C[64];
-};
-constexpr JumpTable make_jump_table()
-{
-    JumpTable t{};
-    uint64_t a = 1, c = 0;
-    for (int n = 0; n < 256; ++n) {
-        if ((n & 3) == 0) { t.A[n >> 2] = a; t.C[n >> 2] = c; }
-        a = a * kPcgMult;
-        c = c * kPcgMult + 1ULL;
-    }
-    return t;
-}
-__device__ const JumpTable kJump4 = make_jump_table();   // entry k: jump by 4k draws
-
 // Cell table in HBM (served from L2 / Infinity Cache): the impulses of every cell (i, j, k) with
 // -H <= i, j, k < H, as float4 (x, y, z, w=+-1) in generation order, `stride` slots per cell.  A wave
 // reads a cell with ONE coalesced 512-B / 1-KiB load; cells outside the table are generated on the
@@ -64,19 +46,6 @@ inline bool fast_supported(const DevModel &M)
 {
     return M.single_realization && !M.sampling_1d && !M.nonstationary && !M.use_aniso_mtx && !M.absorption_only &&
            M.n_impulses >= 1 && M.n_impulses <= 64;
-}
-// one wave per cell: lane k produces impulse k exactly as the sequential generator (SCN.cpp:376-385)
-GPIS_DEV void gen_impulse(uint32_t ci, uint32_t cj, uint32_t ck, uint32_t seed, uint64_t jA, uint64_t jC,
-                          float &px, float &py, float &pz, float &pw)
-{
-    const uint32_t h = xxhash32_4(ck, cj, ci, seed) + 1u;
-    const uint64_t s0 = (uint64_t)h * (kPcgMult * kPcgMult) + (kPcgMult + 1ULL);   // set_state
-    Pcg32 g;
-    g.state = jA * s0 + jC;
-    pz = normalized_uint(g.next_i());
-    py = normalized_uint(g.next_i());
-    px = normalized_uint(g.next_i());
-    pw = (g.next_i() >> 31) ? 1.f : -1.f;   // Bernoulli(next1D(), -1, 1, 0.5)
 }
 __global__ void __launch_bounds__(64) k_fast_build_table(uint32_t seed, int half, int stride, float4 *__restrict__ cells)
 {
@@ -158,65 +127,6 @@ constexpr int kFastBlock = 64;          // one wave per workgroup
 #ifndef GPIS_FAST_OCC
 #define GPIS_FAST_OCC 3                 // waves per SIMD the register allocator must leave room for
 #endif
-typedef float float2v __attribute__((ext_vector_type(2)));    // two fp32 lanes of a v_pk_* instruction
-#ifndef GPIS_LDS_BCAST
-#define GPIS_LDS_BCAST 1                // 1: candidate impulses are broadcast through LDS, 0: with v_readlane
-#endif
-struct FastLds {
-    uint64_t exptab[32];                // glibc's exp2f table, staged once per wave (ds_read_b64 per use)
-#if GPIS_LDS_BCAST
-    // the current cell's impulses, read back at a wave-uniform address (= broadcast), laid out in the
-    // pairs the candidate body consumes with packed fp32 instructions
-    float4 xyr[64];                     // (x, y, kernelRadius * x, kernelRadius * y)
-    float4 zw[64];                      // (z, kernelRadius * z, w = +-1, unused)
-#endif
-};
-GPIS_DEV void fast_lds_init(FastLds &lds)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    if (lane < 32)
-        lds.exptab[lane] = kExp2fTab[lane];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-// wave-uniform value → SGPR
-GPIS_DEV int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-GPIS_DEV float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-// lane k's value, k wave-uniform (v_readlane_b32: no LDS round trip)
-GPIS_DEV float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
-
-// expf_glibc with the table in LDS and the range checks folded into selects (same results).
-// NONPOS: the caller guarantees x <= 0 (or NaN), so the overflow check cannot fire and is left out.
-// NOUNDER: the caller guarantees that every result it USES has x >= -100 (results of smaller x are
-// discarded), so the underflow select is left out as well.
-template <bool NONPOS = false, bool NOUNDER = false>
-GPIS_DEV float expf_glibc_lds(const FastLds &lds, float x)
-{
-    const double InvLn2N = 0x1.71547652b82fep+0 * 32;
-    const double Shift = 0x1.8p+52;
-    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32;
-    const double C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32;
-    const double C2 = 0x1.62e42ff0c52d6p-1 / 32;
-    double z = InvLn2N * (double)x;
-    double kd = z + Shift;
-    uint64_t ki = (uint64_t)__double_as_longlong(kd);
-    uint64_t t = lds.exptab[ki & 31];
-    kd -= Shift;
-    double r = z - kd;
-    t += ki << (52 - 5);
-    double zz = __builtin_fma(C0, r, C1);
-    double r2 = r * r;
-    double y = __builtin_fma(C2, r, 1.0);
-    y = __builtin_fma(zz, r2, y);
-    y = y * __longlong_as_double((long long)t);
-    float res = (float)y;
-    if (!NOUNDER)
-        res = x < -0x1.9fe368p6f ? 0.0f : res;
-    if (!NONPOS)
-        res = x > 0x1.62e42ep6f ? __builtin_huge_valf() : res;
-    return res;
-}
-
 // cold path: every lane generates its own impulses
 GPIS_DEV V4 noise3d_per_lane(const DevModel &M, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
 {

@@ -111,6 +111,11 @@ struct gpis_medium {
     // handle: the last user records an event, the next one makes its stream wait for it
     hipEvent_t ws_event[2];
     bool ws_event_set[2];
+    // persistent march (gpis_persist.inc): ring of ray counters (one per launch in flight), resident-wave budget
+    unsigned int *d_next;
+    unsigned next_slot;
+    int persist_waves[8];    // cached occupancy * CUs per kernel instance; 0 = not queried yet
+    int n_cus;
     bool profiling;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];
     size_t events_used[2];
@@ -378,6 +383,21 @@ __global__ void __launch_bounds__(kBlock, GPIS_GENERIC_OCC) k_transmittance(cons
         }
     }
     flush_counters(cnt, noise.n_eval, nseg);
+}
+
+// persistent refilling form of the two kernels above (gpis_persist.inc): a fixed grid of waves pulls rays from
+// a counter.  Q = slots of the per-lane LDS queue between the impulse generator and the kernel body.
+constexpr int kPersistQ = 16;
+constexpr unsigned kPersistSlots = 256;   // ring of ray counters: one per persistent launch in flight
+#ifndef GPIS_PERSIST_OCC
+#define GPIS_PERSIST_OCC 3   // waves per SIMD of the register allocation (LDS: 12.5 KB per wave -> 12 waves per CU)
+#endif
+template <class P, bool WANT_SAMPLE>
+__global__ void __launch_bounds__(kBlock, GPIS_PERSIST_OCC) k_persist_march(const DevModel *__restrict__ Mp, PersistArgs a)
+{
+    __shared__ PersistQueue<kPersistQ> q;
+    fast_lds_init(q);
+    P::template march<WANT_SAMPLE, kPersistQ>(*Mp, a, q);
 }
 
 __device__ __forceinline__ RayInfo info_of(const gpis_query &q) { return RayInfo{q.pixel[0], q.pixel[1], q.spp, q.segment, q.scene_seed, q.info_t}; }
@@ -1050,6 +1070,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr;
     m->batch_hint = GPIS_ORDER_COHERENT;
     for (int k = 0; k < 2; ++k) { m->ws_event[k] = nullptr; m->ws_event_set[k] = false; }
+    m->d_next = nullptr; m->next_slot = 0; m->n_cus = prop.multiProcessorCount;
+    for (int k = 0; k < 8; ++k) m->persist_waves[k] = 0;
     {   // diagnostic overrides, read here and nowhere else (include/gpis.h: gpis_set_option)
         m->opt[GPIS_OPT_MARCH_FORM] = GPIS_MARCH_FORM_AUTO;
         if (const char *e = getenv("GPIS_MARCH")) {
@@ -1063,6 +1085,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         m->opt[GPIS_OPT_PATHS_PRESORT] = !(e2 && e2[0] == '0');
         m->opt[GPIS_OPT_PERSISTENT] = 1;
         if (const char *e = getenv("GPIS_PERSIST")) m->opt[GPIS_OPT_PERSISTENT] = e[0] != '0';
+        m->opt[GPIS_OPT_SOLO_MAX] = -1;
+        if (const char *e = getenv("GPIS_SOLO_MAX")) m->opt[GPIS_OPT_SOLO_MAX] = atoll(e);
         m->opt[GPIS_OPT_CHUNK_LOG2] = 0;
         if (const char *e = getenv("GPIS_CHUNK_LOG2")) { int l = atoi(e); m->opt[GPIS_OPT_CHUNK_LOG2] = l < 16 ? 16 : (l > 28 ? 28 : l); }
     }
@@ -1076,6 +1100,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     if (e == hipSuccess) e = hipMalloc(&m->d_counters, 2 * sizeof(Counters));
     if (e == hipSuccess) e = hipMalloc(&m->d_guide_cnt, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(m->d_guide_cnt, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&m->d_next, kPersistSlots * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemcpy(m->d_model, &m->host_model, sizeof(DevModel), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(m->d_counters, 0, 2 * sizeof(Counters));
     if (e != hipSuccess) {
@@ -1083,13 +1108,14 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         if (m->d_model) (void)hipFree(m->d_model);
         if (m->d_counters) (void)hipFree(m->d_counters);
         if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
+        if (m->d_next) (void)hipFree(m->d_next);
         delete m;
         return GPIS_ERR_DEVICE;
     }
     st = fast_table_build(m->host_model, m->d_model, &m->fast);
     if (st != GPIS_OK) {
         set_err(st, "gpis_create: building the cell table failed");
-        (void)hipFree(m->d_model); (void)hipFree(m->d_counters); (void)hipFree(m->d_guide_cnt);
+        (void)hipFree(m->d_model); (void)hipFree(m->d_counters); (void)hipFree(m->d_guide_cnt); (void)hipFree(m->d_next);
         delete m;
         return st;
     }
@@ -1114,6 +1140,7 @@ extern "C" int gpis_destroy(gpis_medium *m)
         if (m->ws_event[k]) (void)hipEventDestroy(m->ws_event[k]);
     if (m->d_model) (void)hipFree(m->d_model);
     if (m->d_counters) (void)hipFree(m->d_counters);
+    if (m->d_next) (void)hipFree(m->d_next);
     delete m;
     return GPIS_OK;
 }
@@ -1273,6 +1300,53 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
     return ws_release(m, 1, s);
 }
 
+// ---- persistent march launch (per-path media) ---------------------------------------------------------------
+// the lattice sums of gpis_persist.inc have a diagonal kernel matrix: every medium except world-space 3D with a full anisoMtx
+static bool persist_supported(const DevModel &H) { return H.sampling_1d || H.iso3d || !H.use_aniso_mtx; }
+// sideways (lane = impulse) evaluation pays while at most this many lanes of a wave have a job: lockstep costs
+// 27 n g instructions per round whatever the number of jobs, one sideways job ~20.6 cells x (c0 + c1 n)
+// (g = 61 generator, c0 = 135, c1 = 0.31: counted on the gfx950 ISA of these loops)
+static int persist_solo_max(const gpis_medium *m)
+{
+    const DevModel &H = m->host_model;
+    if (H.sampling_1d || H.n_impulses > 64u || H.n_impulses == 0u) return 0;     // the sideways form holds one cell's impulses in one wave
+    if (m->opt[GPIS_OPT_SOLO_MAX] >= 0) return (int)m->opt[GPIS_OPT_SOLO_MAX];
+    const double lock = 27.0 * H.n_impulses * 61.0, side = 20.6 * (135.0 + 0.31 * H.n_impulses);
+    int t = (int)(lock / side);
+    return t < 0 ? 0 : (t > 48 ? 48 : t);
+}
+template <class P, bool WANT_SAMPLE>
+static int launch_persist_t(gpis_medium *m, int slot_id, PersistArgs a, hipStream_t s)
+{
+    auto kern = k_persist_march<P, WANT_SAMPLE>;
+    if (m->persist_waves[slot_id] == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kBlock, 0) != hipSuccess || nb <= 0) { (void)hipGetLastError(); nb = 8; }
+        m->persist_waves[slot_id] = nb * m->n_cus;
+    }
+    const size_t waves_needed = (a.n + kBlock - 1) / kBlock;
+    const unsigned grid = (unsigned)(waves_needed < (size_t)m->persist_waves[slot_id] ? waves_needed : (size_t)m->persist_waves[slot_id]);
+    a.next = m->d_next + (m->next_slot++ % kPersistSlots);
+    HIP_TRY(hipMemsetAsync(a.next, 0, sizeof(unsigned int), s));
+    kern<<<grid, kBlock, 0, s>>>(m->d_model, a);
+    return launch_check("k_persist_march");
+}
+template <bool WANT_SAMPLE>
+static int launch_persist(gpis_medium *m, PersistArgs a, hipStream_t s)
+{
+    const DevModel &H = m->host_model;
+    if (a.n >= 0xFFFF0000ull) return set_err(GPIS_ERR_INVALID_ARG, "persistent march: batch too large for the 32-bit ray counter");
+    a.solo_max = persist_solo_max(m);
+    const int w = WANT_SAMPLE ? 0 : 4;
+    if (H.sampling_1d)
+        return launch_persist_t<spec_1d::Persist, WANT_SAMPLE>(m, w + 0, a, s);
+    if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid)
+        return launch_persist_t<spec_3d::Persist, WANT_SAMPLE>(m, w + 1, a, s);
+    if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
+        return launch_persist_t<spec_3d_multires::Persist, WANT_SAMPLE>(m, w + 2, a, s);
+    return launch_persist_t<generic::Persist, WANT_SAMPLE>(m, w + 3, a, s);
+}
+
 static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff,
                                 const uint8_t *mask, hipStream_t s, int hint = MARCH_COHERENT)
 {
@@ -1294,6 +1368,11 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
     }
     // pick the instance whose compile-time flags equal the medium's
     const DevModel &H = m->host_model;
+    if (m->opt[GPIS_OPT_PERSISTENT] && persist_supported(H)) {
+        PersistArgs a{};
+        a.n = n; a.rays = rays; a.out = out; a.coeff = coeff; a.visible = nullptr; a.mask = mask; a.cnt = m->d_counters;
+        return launch_persist<true>(m, a, s);
+    }
     const unsigned grid = grid_of(n, kBlock);
     if (H.sampling_1d)
         k_sample_distance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
@@ -1325,6 +1404,11 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
         return launch_check("k_fast_transmittance");
     }
     const DevModel &H = m->host_model;
+    if (m->opt[GPIS_OPT_PERSISTENT] && persist_supported(H)) {
+        PersistArgs a{};
+        a.n = n; a.rays = rays; a.out = nullptr; a.coeff = nullptr; a.visible = visible; a.mask = mask; a.cnt = m->d_counters + 1;
+        return launch_persist<false>(m, a, s);
+    }
     const unsigned grid = grid_of(n, kBlock);
     if (H.sampling_1d)
         k_transmittance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
@@ -1366,6 +1450,7 @@ extern "C" int gpis_set_option(gpis_medium *m, int option, long long value)
     case GPIS_OPT_WAVE_TAIL: CHECK_ARGS(value >= 0); break;
     case GPIS_OPT_PATHS_SORT: case GPIS_OPT_PATHS_PRESORT: case GPIS_OPT_PERSISTENT: CHECK_ARGS(value == 0 || value == 1); break;
     case GPIS_OPT_CHUNK_LOG2: CHECK_ARGS(value == 0 || (value >= 16 && value <= 28)); break;
+    case GPIS_OPT_SOLO_MAX: CHECK_ARGS(value >= -1 && value <= 64); break;
     default: break;
     }
     std::lock_guard<std::mutex> lock(m->mu);

@@ -86,7 +86,7 @@ def test_eval_value_gradient_bit_exact(env, cfg):
     assert e_g >= 2 * len(q)
 
 
-PATHS = ["fast", "fast_gen", "fast_small_table", "generic", "guided_coarse", "guided_fine_partial", "guided_wave", "guided_wave_tail0"]
+PATHS = ["fast", "fast_gen", "fast_small_table", "generic", "generic_lane", "generic_solo", "guided_coarse", "guided_fine_partial", "guided_wave", "guided_wave_tail0"]
 
 
 def _medium(pkg, params, path):
@@ -95,7 +95,9 @@ def _medium(pkg, params, path):
       fast_gen         wave-cooperative kernels, every cell generated on the fly (no table)
       fast_small_table a 4-cell half-extent table: most cells of scene S fall outside it, so table
                        cells and generated cells are mixed inside one evaluation
-      generic          lane-per-ray kernels
+      generic          per-path kernels: persistent refilling march, lockstep lattice sums + sideways tail (the default)
+      generic_lane     the round-1 form: one ray per lane per launch (option "persistent" = 0)
+      generic_solo     persistent march with every lattice sum evaluated sideways (lane = impulse)
       guided_coarse    guided march, guide field over the whole scene at 8 points per cell (loose
                        bound: many steps fall back to the exact evaluation)
       guided_fine_partial  guided march, 32 points per cell but only |u| < 6 cells tabulated: rays
@@ -104,7 +106,8 @@ def _medium(pkg, params, path):
                        every batch; test batches are small, so the one-wave-per-ray tail does most of it
       guided_wave_tail0  the same with the tail kernel disabled: every value goes through step/sort/eval"""
     import os
-    env = {"generic": {"GPIS_DISABLE_FAST": "1"}, "fast_gen": {"GPIS_DISABLE_TABLE": "1"},
+    env = {"generic": {"GPIS_DISABLE_FAST": "1"}, "generic_lane": {"GPIS_DISABLE_FAST": "1"}, "generic_solo": {"GPIS_DISABLE_FAST": "1"},
+           "fast_gen": {"GPIS_DISABLE_TABLE": "1"},
            "fast_small_table": {"GPIS_TABLE_HALF_EXTENT": "4"}, "fast": {}}.get(path, {})
     keys = ("GPIS_DISABLE_FAST", "GPIS_DISABLE_TABLE", "GPIS_TABLE_HALF_EXTENT")
     for k in keys:
@@ -115,7 +118,11 @@ def _medium(pkg, params, path):
     finally:
         for k in keys:
             os.environ.pop(k, None)
-    assert int(med.derived()["fast_path"]) == (0 if path == "generic" else 1)
+    assert int(med.derived()["fast_path"]) == (0 if path.startswith("generic") else 1)
+    if path == "generic_lane":
+        med.set_option("persistent", 0)
+    elif path == "generic_solo":
+        med.set_option("solo_max", 64)
     if path.startswith("guided_wave"):
         med.set_option("march_form", "wave")
         if path.endswith("tail0"):
@@ -332,6 +339,97 @@ def test_1d_sampling_and_nee(env, ctx, xy, scheme):
     assert np.isfinite(pdf_o).mean() > 0.99 and (pdf_o[np.isfinite(pdf_o)] >= 0).all()
 
 
+def _persist_cases(pkg):
+    c0 = pkg.params_for_config("C0"); c0["single_realization"] = 0; c0["correlation_context"] = pkg.CTX.RENEWAL
+    c1 = pkg.params_for_config("C1"); c1["single_realization"] = 0; c1["correlation_context"] = pkg.CTX.RENEWAL_PLUS
+    c1a = c1.copy(); c1a["aniso"] = (1.0, 0.6, 1.7); c1a["impulse_density"] = 20
+    c2 = pkg.params_for_config("C2")
+    c2r = c2.copy(); c2r["correlation_context"] = pkg.CTX.RENEWAL; c2r["correlation_xy"] = 0
+    c3 = pkg.params_for_config("C3"); c3["impulse_density"] = 16; c3["correlation_context"] = pkg.CTX.RENEWAL_PLUS
+    c3w = c3.copy(); c3w["isotropic_3d_sampling"] = 0
+    c3d = c3.copy(); c3d["sampling_1d"] = 1
+    ns = pkg.params_for_config("C3"); ns["impulse_density"] = 8; ns["multi_resolution_grid"] = 0; ns["isotropic_3d_sampling"] = 0
+    ab = c0.copy(); ab["sigma_s"] = 0.0; ab["sigma_a"] = 1.0; ab["correlation_context"] = pkg.CTX.RENEWAL_PLUS
+    big = pkg.params_for_config("C0"); big["single_realization"] = 0; big["impulse_density"] = 80   # > 64: no sideways form
+    return {"C0pp": c0, "C1pp": c1, "C1pp_aniso": c1a, "C2": c2, "C2_renewal": c2r, "C3_16": c3, "C3_world": c3w, "C3_1d": c3d,
+            "nonstat": ns, "absorb": ab, "rho80": big}
+
+
+@pytest.mark.parametrize("case", ["C0pp", "C1pp", "C1pp_aniso", "C2", "C2_renewal", "C3_16", "C3_world", "C3_1d", "nonstat", "absorb", "rho80"])
+def test_persistent_march_equals_lane_per_ray(env, case):
+    """The persistent refilling kernels (lockstep lattice sums with deferred kernel bodies; sideways sums for thin waves)
+    against the one-ray-per-lane kernels on the same device: every output byte, the conditioning coefficients, the per-ray
+    evaluation counts and the device counters must be identical — also for the configurations whose parity with the
+    oracle carries a tolerance (both forms run the same device libm)."""
+    pkg, ob, lib = env
+    params = _persist_cases(pkg)[case]
+    twin = params.copy()
+    twin["sigma_s"] = 1.0                      # the rays' second segments start from a scattering twin's hits
+    orc = ob.Oracle(twin, threads=16)
+    scene = ob.default_scene_s(96, 54, 2)
+    rays, us = scene_rays(ob, orc, scene, step=2)
+    first = orc.sample_distance(rays)
+    sh = shadow_rays_from(ob, scene, rays, us, first)
+    batch = np.concatenate([rays, sh]) if len(sh) else rays
+    batch = batch.copy()
+    batch["far_t"][0] = 0.0; batch["near_t"][0] = 0.0          # maxT == 0 shortcut
+    batch["bounce"][1] = 5000                                  # bounce limit
+    ref = pkg.Medium(params)
+    ref.set_option("persistent", 0)
+    want, cw = ref.sample_distance(batch, want_coeff=True)
+    vis_w = ref.transmittance(batch)
+    e_w = ref.counters()
+    if case == "absorb":
+        assert (want["exited"] == 1).all() and (want["weight"][:, 0] == 0).sum() > 20 and (want["weight"][:, 0] == 1).sum() > 20
+    else:
+        assert (want["exited"] == 0).sum() > 20 and (want["exited"] == 1).sum() > 20
+    for solo in (-1, 0, 64, 5):
+        med = pkg.Medium(params)
+        assert med.get_option("persistent") == 1
+        med.set_option("solo_max", solo)
+        got, cg = med.sample_distance(batch, want_coeff=True)
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], want[f], equal_nan=True), (case, solo, f)
+        for f in cg.dtype.names:
+            assert np.array_equal(cg[f], cw[f], equal_nan=True), (case, solo, "coeff", f)
+        assert np.array_equal(med.transmittance(batch), vis_w), (case, solo)
+        assert med.counters() == e_w, (case, solo)
+        # a masked, offset sub-batch through the device entry: ray order and refill order do not matter
+        sub = batch[::-1][:257].copy()
+        d_r, d_o = to_dev(sub), dev_empty(len(sub) * pkg.SEG_OUT.itemsize)
+        med.call("gpis_sample_distance_batch", ctypes.c_size_t(len(sub)), d_r.data_ptr(), d_o.data_ptr(), None, stream_ptr())
+        assert np.array_equal(to_host(d_o, pkg.SEG_OUT), want[::-1][:257])
+
+
+def test_c3_at_its_own_impulse_density(env):
+    """Config C3 as BASELINE.json states it — multi-resolution, impulse_density = 64, per-path realizations, renewal —
+    against the oracle (toleranced: the length-scale ramp goes through device log/exp)."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C3")
+    assert params["impulse_density"] == 64 and params["multi_resolution_grid"] == 1 and params["single_realization"] == 0
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    q = _queries(pkg, 512, 33)
+    assert _close(med.eval_value(q)[0], orc.eval_value(q)[0])
+    assert _close(med.eval_gradient(q), orc.eval_gradient(q), 1e-4, 1e-4)
+    scene = ob.default_scene_s(96, 54, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    assert len(rays) > 150
+    got, want = med.sample_distance(rays, want_coeff=True), orc.sample_distance(rays, want_coeff=True)
+    flips = int((got[0]["exited"] != want[0]["exited"]).sum())
+    print("C3 rho=64: %d rays, %d hit/miss flips" % (len(rays), flips))
+    assert flips <= max(1, len(rays) // 300)
+    same = got[0]["exited"] == want[0]["exited"]
+    assert _close(got[0]["t"][same], want[0]["t"][same], 1e-4, 1e-4)
+    assert _close(got[0]["aniso"][same], want[0]["aniso"][same], 1e-3, 1e-3)
+    sh = shadow_rays_from(ob, scene, rays, us, want[0])
+    assert len(sh) > 20
+    g2, w2 = med.sample_distance(sh, want_coeff=True), orc.sample_distance(sh, want_coeff=True)
+    flips2 = int((g2[0]["exited"] != w2[0]["exited"]).sum())
+    assert flips2 <= max(1, len(sh) // 300)
+    assert _close(g2[1]["value_scale"], w2[1]["value_scale"], 1e-3, 1e-4)
+    assert (med.transmittance(sh) != orc.transmittance(sh)).sum() <= max(1, len(sh) // 300)
+
+
 @pytest.mark.parametrize("iso,oned", [(1, 0), (0, 0), (1, 1)])
 def test_multi_resolution_nonstationary(env, iso, oned):
     """Config C3 family: procedural length-scale ramp + two-level multi-resolution blend."""
@@ -488,7 +586,7 @@ def test_render_scene_s_small(env, path):
         e_g, s_g = med.counters()
         e_o, s_o = orc.counters()
         assert s_g == s_o
-        if path == "generic":
+        if path.startswith("generic"):
             assert e_g == e_o
         elif path.startswith("guided"):
             # certified steps replace exact evaluations: fewer evaluations, some guide lookups
