@@ -4,13 +4,14 @@
 A "step" renders one full frame of the configuration BASELINE.json quotes the metric on
 (C1: 1920x1080, 64 spp, 3D isotropic sampling, impulse_density=32, renewal, single realization):
 primary sampleDistance, shading, one shadow transmittance per hit, per-pixel accumulation.
-Inputs (the medium's constants, the workspace) are resident in HBM before the timed region.
+Inputs (the medium's constants, the guide field, the workspace) are resident in HBM before the timed
+region; `value_cold` is the same frame with every one-off cost inside the timer, `value_unguided` the
+frame without the guide field (every march step evaluated exactly).
 
-Multi-GPU (one process per GPU, torch.distributed / RCCL): rank 0 broadcasts the parameter
-block; rank r renders sample indices [r*spp, (r+1)*spp) of every pixel (per-GPU work is fixed:
-weak scaling; every sample's randomness is a function of (pixel, spp index) only, so the sharded
-image equals the single-GPU image at spp*N); the per-rank radiance sums are reduced to rank 0
-inside the timed region (the one exchange step of the path).
+`python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed / RCCL): rank 0
+broadcasts the parameter block, the image's 16-pixel tile rows are dealt round-robin to the ranks (the tile
+split of the reference's integrator: the SAME image at every N, strong scaling), and the disjoint partial
+images are assembled with ONE reduce(sum) to rank 0 inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,6 +29,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md "Chip-level parameters")
 B_SEG = 224                    # bytes per segment: 128 in + 96 out
+N_SIMD = 256 * 4               # CUs x SIMDs
+PEAK_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md "Max clock"
+ISSUE_MODEL = os.path.join(ROOT, "profiles", "r02_issue_model.json")
 
 
 def algorithmic_bytes_per_eval(params):
@@ -37,28 +41,54 @@ def algorithmic_bytes_per_eval(params):
     return (3 * rho * 8 * L) if params["sampling_1d"] else (27 * rho * 16 * L)
 
 
-def algorithmic_ops_per_eval(params):
-    """SURVEY.md §8d, secondary figure for the VALU roof: 27*[H + (2+4*rho)*P + rho*D] + 0.155*27*rho*K
-    with H=24 (hash), P=14 (PCG draw), D=10 (distance test), K=40 (kernel); 3 cells and 2 draws per impulse in 1D."""
-    rho = int(params["impulse_density"])
-    L = 2 if (params["nonstationary"] and params["multi_resolution_grid"]) else 1
-    if params["sampling_1d"]:
-        return L * (3 * (24 + (2 + 2 * rho) * 14 + rho * 6) + 3 * rho * 40)
-    return L * (27 * (24 + (2 + 4 * rho) * 14 + rho * 10) + 0.155 * 27 * rho * 40)
+def library_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12      # one simple VALU op per lane and clock: 39.3 Tops/s (MI355X_MICROARCH.md: 157.3 TF = x2 packed x2 FMA)
+def issue_roofline(kernel, workload_key, avg_launch_ms, lib_path):
+    """The dominant kernel against the roof that binds it: vector-instruction ISSUE.
 
-
-def load_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
+    achieved = the issue cycles one launch of the kernel needs — per PMC instruction class, the counted wave
+               instructions (rocprofv3 --pmc SQ_INSTS_VALU_*, profiles/) x the measured issue cost of that class
+               (tools/valu_issue_bench: 2 SIMD cycles for a full-rate wave64 op, 4 for f64 / packed f32 / 32-bit
+               multiply / 3-operand integer ops, 8 for transcendentals and v_readlane; profiles/) — divided by the
+               launch duration measured live with HIP events in this run;
+    peak     = 1024 SIMDs x 2.4 GHz: every SIMD issuing on every cycle of the launch (the launch cannot use more).
+    The counters belong to one launch of the SAME workload with the SAME library (sha256 compared); they are
+    deterministic for it.  `traffic` = FETCH_SIZE + WRITE_SIZE of the same launch."""
+    if not os.path.exists(ISSUE_MODEL):
         return None
     try:
-        return json.load(open(path)).get(kernel_key)
+        model = json.load(open(ISSUE_MODEL))
     except Exception:
         return None
+    k = model.get("kernels", {}).get(kernel)
+    if k is None or model.get("workload") != workload_key:
+        return {"bound": "valu_issue", "kernel": kernel, "achieved": None, "peak": N_SIMD * PEAK_CLOCK_HZ / 1e12, "unit": "T SIMD issue cycles/s",
+                "frac": None, "traffic": None, "note": "no committed instruction counters for this kernel / workload (%s)" % workload_key}
+    stale = model.get("so_sha256") != library_sha256(lib_path)
+    sec = avg_launch_ms * 1e-3
+    peak = N_SIMD * PEAK_CLOCK_HZ
+    cyc = k["issue_cycles"]
+    traffic = (k["traffic_bytes"]["fetch"] + k["traffic_bytes"]["write"]) if k.get("traffic_bytes") else None
+    return {
+        "bound": "valu_issue", "kernel": kernel,
+        "achieved": cyc["model"] / sec / 1e12, "peak": peak / 1e12, "unit": "T SIMD issue cycles/s",
+        "frac": cyc["model"] / sec / peak, "frac_range": [cyc["lo"] / sec / peak, (cyc["hi"] / sec / peak) if cyc.get("hi") else None],
+        "traffic": traffic,
+        "hbm": None if traffic is None else {"bytes_per_launch": traffic, "GBps": traffic / sec / 1e9, "frac_of_peak": traffic / sec / 1e9 / HBM_PEAK_GBS,
+                                              "compulsory_bytes_per_launch": k.get("compulsory_bytes")},
+        "issue_cycles_per_launch": cyc, "valu_instructions_per_launch": k["valu_insts"],
+        "mean_cycles_per_valu_instruction": cyc["model"] / max(k["valu_insts"], 1),
+        "fit": {"relative_residual": k["fit"]["relative_residual"], "loops_used": k["fit"]["loops_used"]} if k.get("fit") else None,
+        "avg_launch_ms": avg_launch_ms, "profiled_launch_ms": k.get("launch_ms_profiled"),
+        "counters_source": "profiles/r02_issue_model.json (" + model.get("collected", "") + ")", "counters_stale": stale,
+    }
 
 
 def usable_cores():
@@ -179,6 +209,7 @@ def main():
                     "single-realization media, or 'off' (built once before the timed region: 34 GB / 3.3 s at 16:64, "
                     "4.3 GB / 0.3 s at 16:32; falls back to 16:32 if the allocation fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unguided", action="store_true", help="skip the extra unguided frame (value_unguided)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -208,6 +239,20 @@ def main():
     params = pkg.params_for_config(args.config) if rank == 0 else np.zeros((), dtype=pkg.PARAMS)
     params = pkg.dist.broadcast_params(params, pkg.PARAMS, dist, device="cuda")
 
+    W, H, spp = args.width, args.height, args.spp
+    scene = pkg.default_scene_s(W, H, spp)
+    rad = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- cold frame: everything a first frame pays — medium constants + cell table, guide field, the driver's
+    #      workspace (50 GB for a C1 frame) and the frame itself — inside ONE timer
+    fence()
+    t_cold0 = time.perf_counter()
     med = pkg.Medium(params, device=local_rank)
     lib = med.L.lib
     guide_info = None
@@ -221,27 +266,20 @@ def main():
             med.build_guide(half, ppc)
         guide_info = {"half_extent_cells": half, "points_per_cell": ppc, "bytes": (2 * half * ppc) ** 3 * 4,
                       "build_s": time.perf_counter() - t_g}
-    W, H, spp = args.width, args.height, args.spp
-    scene = np.zeros((), dtype=pkg.SCENE_S)
-    lib.gpis_default_scene_s(scene.ctypes.data, W, H, spp)
-    rad = torch.zeros(H * W, dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
 
     def render_into(part, acc):
         med.call("gpis_render_scene_s", part.ctypes.data_as(ctypes.c_void_p), acc.data_ptr(), None, stream)
 
     def step():
         rad.zero_()
-        # weak scaling ("spp"): each rank renders its own spp slice of every pixel, then one
-        # reduce(sum) to rank 0; "rows" deals 16-pixel tile rows round-robin (strong scaling)
+        # "rows": 16-pixel tile rows dealt round-robin, one batch per rank, one reduce(sum) of the disjoint partial images
         pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    step()
+    fence()
+    dt_cold = time.perf_counter() - t_cold0
 
-    step()      # set-up, like the guide build: the first render allocates the driver's workspace (50 GB for a C1 frame)
+    # ---- warm frames: the metric
     for _ in range(args.warmup):
         step()
     fence()
@@ -255,59 +293,69 @@ def main():
     dt = time.perf_counter() - t0
     med.set_profiling(False)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt, dt_cold], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_max, dt_cold_max = float(tt[0].item()), float(tt[1].item())
 
     prof = [med.kernel_profile(k) for k in (0, 1)]     # (ms, launches, n_eval, n_seg)
     n_guide = med.guide_steps() if guide_info else 0
+
+    # ---- the same frame without the guide field: every march step evaluated exactly (N = 1 only; one frame)
+    dt_unguided = None
+    if guide_info and world == 1 and not args.no_unguided:
+        med.drop_guide()
+        fence()
+        t1 = time.perf_counter()
+        step()
+        fence()
+        dt_unguided = time.perf_counter() - t1
+
     if rank == 0:
-        total_samples = W * H * pkg.dist.total_spp(scene, world, args.shard) * args.steps
+        samples_per_step = W * H * pkg.dist.total_spp(scene, world, args.shard)
+        total_samples = samples_per_step * args.steps
         b_eval = algorithmic_bytes_per_eval(params)
         names = ("sample_distance", "transmittance")
         dom = 0 if prof[0][0] >= prof[1][0] else 1
         ms, launches, n_eval, n_seg = prof[dom]
-        bytes_alg = n_eval * b_eval + n_seg * B_SEG
-        achieved = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        # the same figure priced at the evaluations the REFERENCE algorithm performs on these segments:
-        # every march step the guide certified stands for one evaluateValue of GPM.cpp:189-193
-        n_eval_all = prof[0][2] + prof[1][2] + n_guide
+        n_eval_all = prof[0][2] + prof[1][2]
         n_seg_all = prof[0][3] + prof[1][3]
-        ms_all = prof[0][0] + prof[1][0]
-        ref_equiv = (n_eval_all * b_eval + n_seg_all * B_SEG) / (ms_all * 1e-3) / 1e9 if ms_all > 0 else 0.0
         fast = int(med.derived()["fast_path"])
-        kernel = ("k_guided_" if guide_info else ("k_fast_" if fast else "k_")) + names[dom]
+        persistent = (not fast) and med.get_option("persistent") == 1
+        kernel = ("k_guided_" if guide_info else ("k_fast_" if fast else ("k_persist_march_" if persistent else "k_"))) + names[dom]
+        workload_key = "%s %dx%dx%d guide %s n_gpus %d" % (args.config, W, H, spp, ("%d:%d" % (guide_info["half_extent_cells"], guide_info["points_per_cell"])) if guide_info else "off", world)
+        roof = issue_roofline(kernel, workload_key, ms / max(launches, 1), med.L.path)
+        if roof is None:
+            roof = {"bound": "valu_issue", "kernel": kernel, "achieved": None, "peak": N_SIMD * PEAK_CLOCK_HZ / 1e12, "unit": "T SIMD issue cycles/s",
+                    "frac": None, "traffic": None, "note": "profiles/r02_issue_model.json not found"}
+        if True:
+            roof["kernel_ms"] = {names[0]: prof[0][0], names[1]: prof[1][0]}
+            roof["launches"] = launches
+            roof["evals_per_s"] = n_eval_all / dt_max
+            roof["certified_steps_per_s"] = n_guide / dt_max
+            # SURVEY.md 8d's bookkeeping figures — labelled, and never divided by a hardware peak: impulses are generated
+            # or served from cache, not loaded from HBM, and one generated impulse serves the 64 queries of a wave
+            roof["algorithmic"] = {"bytes_per_eval": b_eval, "bytes_per_segment": B_SEG, "n_eval": n_eval, "n_seg": n_seg,
+                                   "certified_steps": n_guide,
+                                   "reference_equivalent_evals_per_s": (n_eval_all + n_guide) / dt_max,
+                                   "doc": "exact evaluations the kernels performed; a certified march step stands for one evaluateValue of the reference"}
         res = {
             "metric": "Msamples/s (primary rays x spp / s)", "value": total_samples / dt_max / 1e6, "unit": "Msamples/s",
+            "value_cold": samples_per_step / dt_cold_max / 1e6,
+            "value_unguided": (samples_per_step / dt_unguided / 1e6) if dt_unguided else None,
             "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.shard == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: scene S %dx%d, %d spp/GPU, SparseConvolutionNoiseMedium (3D isotropic, "
+            "config": {"workload": "%s: scene S %dx%d, %d spp, SparseConvolutionNoiseMedium (3D isotropic, "
                                    "impulse_density=%d, ctx=renewal, single_realization)" % (args.config, W, H, spp, int(params["impulse_density"]))
-                       if args.config == "C1" else "%s: scene S %dx%d, %d spp/GPU" % (args.config, W, H, spp),
-                       "sharding": ("%s shards per rank + reduce(sum) to rank 0" % args.shard) if world > 1 else "single GPU",
+                       if args.config == "C1" else "%s: scene S %dx%d, %d spp" % (args.config, W, H, spp),
+                       "sharding": ("%s: 16-pixel tile rows dealt round-robin, one batch per rank, reduce(sum) of disjoint partial images to rank 0" % args.shard
+                                    if args.shard == "rows" else "spp slices per rank + reduce(sum) to rank 0") if world > 1 else "single GPU",
                        "kernel_path": ("guided (certified guide field + wave-cooperative exact evaluations)" if guide_info else
-                                       "fast (wave-cooperative)") if fast else "generic (on-the-fly impulses)",
-                       "guide": guide_info},
-            "roofline": {
-                "bound": "hbm", "kernel": kernel,
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(kernel),
-                "algorithmic_bytes_per_launch": bytes_alg / max(launches, 1),
-                "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-                "bytes_per_eval": b_eval, "bytes_per_segment": B_SEG, "n_eval": n_eval, "n_seg": n_seg,
-                "evals_per_s": (prof[0][2] + prof[1][2]) / dt_max,
-                "certified_steps": n_guide, "certified_steps_per_s": n_guide / dt_max,
-                "valu": {"doc": "secondary roof (SURVEY.md 8d): algorithmic VALU ops of the exact evaluations the dominant kernel performed / its time; "
-                                "exceeds the peak because one generated or gathered impulse serves the 64 queries of a wave",
-                         "ops_per_eval": algorithmic_ops_per_eval(params), "achieved_Tops": n_eval * algorithmic_ops_per_eval(params) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                         "peak_Tops": VALU_PEAK_TOPS},
-                "reference_equivalent": {"evals": n_eval_all, "segments": n_seg_all, "GBps": ref_equiv,
-                                         "doc": "both medium kernels, counting a certified march step as the evaluation it replaces"},
-                "kernel_ms": {names[0]: prof[0][0], names[1]: prof[1][0]},
-                "note": "impulses are generated or gathered on chip; the binding roof is VALU integer/fp32 issue, "
-                        "the HBM figure uses SURVEY.md 8d's algorithmic-bytes definition",
-            },
+                                       "fast (wave-cooperative)") if fast else ("per-path: persistent refilling march" if persistent else "per-path: one ray per lane"),
+                       "guide": guide_info,
+                       "value_cold_doc": "one frame with gpis_create (cell table), the guide-field build and the workspace allocation inside the timer (%.2f s)" % dt_cold_max,
+                       "value_unguided_doc": "one frame after gpis_drop_guide: every march step is an exact wave-cooperative evaluation" if dt_unguided else None},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             cores = usable_cores()

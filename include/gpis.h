@@ -29,7 +29,7 @@
  * Environment: a few diagnostic overrides are read ONCE, in gpis_create, as the initial values
  * of the options below and of the cell table: GPIS_MARCH=resident|wave, GPIS_WAVE_TAIL=<rays>,
  * GPIS_PATHS_SORT=0, GPIS_PATHS_PRESORT=0, GPIS_CHUNK_LOG2=<16..28>, GPIS_DISABLE_FAST=1,
- * GPIS_DISABLE_TABLE=1, GPIS_TABLE_HALF_EXTENT=<cells>, GPIS_PERSIST=0, GPIS_SOLO_MAX=<lanes>.  Nothing is read from
+ * GPIS_DISABLE_TABLE=1, GPIS_TABLE_HALF_EXTENT=<cells>, GPIS_PERSIST=0, GPIS_SOLO_MAX=<lanes>, GPIS_RANGE_LEN=<rays>.  Nothing is read from
  * the environment after gpis_create.  Results never depend on any of them.
  *
  * All functions return GPIS_OK (0) or a negative gpis_status; gpis_last_error()
@@ -297,7 +297,14 @@ int gpis_xxhash32_batch(gpis_medium *m, size_t n, int arity, const uint32_t *wor
 int gpis_pcg32_stream_batch(gpis_medium *m, size_t n, const uint64_t *state, uint32_t count,
                             uint32_t *out, void *stream);
 
-/* ---- host-pointer conveniences (synchronous) ------------------------------------ */
+/* ---- host-pointer entries (synchronous) ------------------------------------------
+ * What a `Medium` adapter inside the reference calls (a batch of one per sampleDistance / transmittance), and what a
+ * host-side wavefront integrator calls with whole batches.  The two march entries move their records in chunks of
+ * 262 144 through two streams (H2D, kernel and D2H of consecutive chunks overlap).  Buffers obtained from
+ * gpis_alloc_host (pinned memory) are transferred by DMA directly; any other host memory is staged through pinned
+ * buffers of the handle with one extra memcpy each way. */
+void *gpis_alloc_host(size_t bytes);      /* pinned host memory; NULL on failure */
+void gpis_free_host(void *p);
 int gpis_sample_distance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays,
                               gpis_seg_out *out, gpis_cond_coeff *coeff);
 int gpis_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible);
@@ -341,6 +348,8 @@ typedef enum gpis_option {
     GPIS_OPT_PERSISTENT = 5,     /* per-path media: 1 (default) = persistent refilling march kernels, 0 = one ray per lane per launch */
     GPIS_OPT_SOLO_MAX = 6,       // persistent march: evaluate sideways (lane = impulse) while at most this many lanes of a wave have a
                                  //   pending evaluation; -1 (default) = derived from impulse_density
+    GPIS_OPT_RANGE_LEN = 7,      // guided march (resident form): 0 (default) = one ray per lane per launch; > 0 = rays per wave with
+                                 //   in-wave refill as segments finish (multiple of 64; measured slower on camera rays)
     GPIS_OPT_COUNT_
 } gpis_option;
 typedef enum gpis_march_form { GPIS_MARCH_FORM_AUTO = 0, GPIS_MARCH_FORM_RESIDENT = 1, GPIS_MARCH_FORM_WAVE = 2 } gpis_march_form;

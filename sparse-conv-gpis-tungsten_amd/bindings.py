@@ -199,7 +199,8 @@ def params_for_config(name):
 
 
 def library_path():
-    return os.path.join(_HERE, "csrc", "libgpis_hip.so")
+    # GPIS_LIBRARY: a differently tuned build of the same sources (tools/ experiments); the ABI check below still applies
+    return os.environ.get("GPIS_LIBRARY") or os.path.join(_HERE, "csrc", "libgpis_hip.so")
 
 
 def _ptr(a):
@@ -219,7 +220,7 @@ class GpisLib:
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
         "gpis_xxhash32_batch", "gpis_pcg32_stream_batch",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
-        "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host",
+        "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
         "gpis_set_batch_order", "gpis_set_option", "gpis_get_option", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
         "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
@@ -265,6 +266,10 @@ class GpisLib:
         L.gpis_conditioning_host.argtypes = [vp, sz, vp, vp, vp, vp]
         L.gpis_nee_pdf_host.argtypes = [vp, sz, vp, vp]
         L.gpis_nee_grad_host.argtypes = [vp, sz, vp, vp]
+        L.gpis_alloc_host.argtypes = [sz]
+        L.gpis_alloc_host.restype = vp
+        L.gpis_free_host.argtypes = [vp]
+        L.gpis_free_host.restype = None
         L.gpis_get_counters.argtypes = [vp, vp, vp]
         L.gpis_reset_counters.argtypes = [vp]
         L.gpis_set_profiling.argtypes = [vp, i32]
@@ -422,7 +427,7 @@ class Medium:
     def set_batch_order(self, scattered):
         self.L.check(self.L.lib.gpis_set_batch_order(self.h, 1 if scattered else 0), "gpis_set_batch_order")
 
-    OPTIONS = {"march_form": 0, "wave_tail": 1, "paths_sort": 2, "paths_presort": 3, "chunk_log2": 4, "persistent": 5, "solo_max": 6}
+    OPTIONS = {"march_form": 0, "wave_tail": 1, "paths_sort": 2, "paths_presort": 3, "chunk_log2": 4, "persistent": 5, "solo_max": 6, "range_len": 7}
     MARCH_FORMS = {"auto": 0, "resident": 1, "wave": 2}
 
     def set_option(self, name, value):

@@ -121,6 +121,19 @@ struct Pcg32 {
         state = s * (kPcgMult * kPcgMult) + (kPcgMult + 1ULL);
     }
 };
+// the output permutation of next_i() for a given (old) state, and the LCG advanced by 1..4 draws in closed form:
+// state_{+j} = A_j * state + C_j (mod 2^64).  The four draws of one impulse then hang off ONE state instead of a chain
+// of four dependent 64-bit multiply-adds (same values, 4x shorter dependency chain in the lockstep generator loop).
+GPIS_DEV uint32_t pcg_output(uint64_t old)
+{
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return __builtin_rotateright32(xs, rot);
+}
+constexpr uint64_t kPcgA1 = kPcgMult, kPcgC1 = 1ULL;
+constexpr uint64_t kPcgA2 = kPcgA1 * kPcgMult, kPcgC2 = kPcgC1 * kPcgMult + 1ULL;
+constexpr uint64_t kPcgA3 = kPcgA2 * kPcgMult, kPcgC3 = kPcgC2 * kPcgMult + 1ULL;
+constexpr uint64_t kPcgA4 = kPcgA3 * kPcgMult, kPcgC4 = kPcgC3 * kPcgMult + 1ULL;
 GPIS_DEV float normalized_uint(uint32_t i) { return __uint_as_float((i >> 9u) | 0x3F800000u) - 1.0f; }
 
 // ---------------------------------------------------------------------------------------
@@ -366,6 +379,8 @@ struct FastLds {
     float4 xyr[64];                     // (x, y, kernelRadius * x, kernelRadius * y)
     float4 zw[64];                      // (z, kernelRadius * z, w = +-1, unused)
 #endif
+    // lane tables of the two-way candidate split (coop_noise3d): the r-th lane with a query / the r-th lane without one
+    uint32_t owner_tab[64], idle_tab[64];
 };
 template <class LDS>
 GPIS_DEV void fast_lds_init(LDS &lds)

@@ -141,14 +141,39 @@ GPIS_DEV V4 noise3d_per_lane(const DevModel &M, V3 p, uint32_t seed, float R, fl
 // SMALLARG: max_a(A_a) * R^2 < 100 for this medium (DevModel::exp_arg_max, checked by the launcher): a lane
 // that passes the unit-ball test has ab^T A ab < 100, far from expf's underflow threshold (103.97), and the
 // value computed for a failing lane is discarded — the underflow select of expf is dead code there.
+// SPLIT (value only, wave-uniform `split`): when at most 32 lanes hold a query, every query gets a HELPER lane from the
+// idle half of the wave.  Candidates are consumed two per pass as before — cell = (cell + c(k0)) + c(k1) — but the
+// owner evaluates c(k0) while its helper evaluates c(k1) on a copy of the same query point, and one ds_bpermute hands
+// c(k1) over: the same values added in the same order, with half the kernel-body instructions per query
+// (the exact rounds of the guided march run with ~30 of 64 lanes).
 template <bool GRAD, bool SMALLARG = false>
-GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
+GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, uint32_t seed, float R, float A0, float A1, float A2,
+                         bool split = false)
 {
     const int lane = (int)(threadIdx.x & 63);
     V3 pg = p / R;
     V3 fl = v3(floorf(pg.x), floorf(pg.y), floorf(pg.z));
     V3 frac = pg - fl;
     int ci0 = (int)fl.x, cj0 = (int)fl.y, ck0 = (int)fl.z;
+    bool helper = false;
+    int partner = lane;
+    if (!GRAD && split) {
+        const unsigned long long am = __ballot(active);
+        const int na = __popcll(am);
+        const int rank_a = __popcll(am & ((1ULL << lane) - 1ULL)), rank_i = lane - rank_a;
+        if (active) lds.owner_tab[rank_a] = (uint32_t)lane;
+        else lds.idle_tab[rank_i] = (uint32_t)lane;
+        helper = !active && rank_i < na;
+        // one wave per workgroup and in-order LDS: only the compiler has to be told that lanes talk to each other here
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        partner = active ? (int)lds.idle_tab[rank_a] : (helper ? (int)lds.owner_tab[rank_i] : lane);
+        // the helper works on a copy of its owner's query
+        const float hx = __shfl(frac.x, partner, 64), hy = __shfl(frac.y, partner, 64), hz = __shfl(frac.z, partner, 64);
+        const int hi = __shfl(ci0, partner, 64), hj = __shfl(cj0, partner, 64), hk = __shfl(ck0, partner, 64);
+        if (helper) { frac = v3(hx, hy, hz); ci0 = hi; cj0 = hj; ck0 = hk; }
+    }
+    const bool act2 = active || helper;
 
     // bounding box of the active lanes' grid positions (inactive lanes contribute nothing)
     const float big = 3.0e38f;
@@ -221,7 +246,7 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
         if (c + 1 < total && in_table(ci, cj, ck))
             nxt = fetch(ci, cj, ck);
         const int di = ti - ci0, dj = tj - cj0, dk = tk - ck0;
-        const bool mine = active && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
+        const bool mine = act2 && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
         FSTAT(2, 1);
         if (__ballot(mine) == 0ULL)
             continue;
@@ -321,6 +346,20 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
         };
 #endif
         V4 cell = v4(0.f, 0.f, 0.f, 0.f);
+        if (!GRAD && split) {
+            while (cand) {
+                const int k0 = __builtin_ctzll(cand);
+                cand &= cand - 1ULL;
+                int k1 = -1;
+                if (cand) { k1 = __builtin_ctzll(cand); cand &= cand - 1ULL; }
+                const float c = contribution((helper && k1 >= 0) ? k1 : k0).v;      // owner: c(k0); helper: c(k1)
+                const float co = __shfl(c, partner, 64);
+                if (k1 >= 0) cell.v = (cell.v + c) + co;                             // meaningful on the owners
+                else cell.v = cell.v + c;
+            }
+            sum.v = sum.v + cell.v;
+            continue;
+        }
         while (cand) {
             const int k0 = __builtin_ctzll(cand);
             cand &= cand - 1ULL;
@@ -474,18 +513,18 @@ GPIS_DEV float solo_noise3d_value_packed(const DevModel &M, const FastTable &T, 
 // `coord` is the ray's isotropic-ray frame (SCN.cpp:296-297), constant along the segment and hoisted
 // out of the march by the caller.
 template <bool GRAD, bool SMALLARG = false>
-GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval)
+GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, uint32_t &n_eval, bool split = false)
 {
     if (active) n_eval++;
     if (!M.iso3d) {
         float R = M.radius_world;
         // getInvCovMtx(isCov=false, isIsotropic=false, globalScale=1, localScale=1): ((A / 1) / 1) * 0.5
         float A0 = M.invcov_world[0] / 1.f / 1.f * 0.5f, A1 = M.invcov_world[4] / 1.f / 1.f * 0.5f, A2 = M.invcov_world[8] / 1.f / 1.f * 0.5f;
-        V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p, M.seed, R, A0, A1, A2);
+        V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p, M.seed, R, A0, A1, A2, split);
         return nz / M.norm3d_world;
     }
     V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
-    V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f);
+    V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f, split);
     if (GRAD) {
         V3 gw = cov_grad_l2w(M, to_global(coord, v3(nz.gx, nz.gy, nz.gz)), 1.0f);
         return v4(nz.v, gw.x, gw.y, gw.z) / M.norm3d_iso;
@@ -495,9 +534,10 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &ld
 
 // evaluateValue, SCN.cpp:73-89
 template <bool SMALLARG = false>
-GPIS_DEV float coop_evaluate_value(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval)
+GPIS_DEV float coop_evaluate_value(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, const Frame &coord, int &gp_id, uint32_t &n_eval,
+                                   bool split = false)
 {
-    float nv = coop_eval_noise3d<false, SMALLARG>(M, T, lds, active, p, coord, n_eval).v;
+    float nv = coop_eval_noise3d<false, SMALLARG>(M, T, lds, active, p, coord, n_eval, split).v;
     double mean;
     int id;
     mean_weight_space(M, to_d(p), mean, id);

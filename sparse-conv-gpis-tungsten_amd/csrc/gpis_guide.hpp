@@ -64,6 +64,10 @@ struct GuideField {
 #ifndef GPIS_SOLO_MAX
 #define GPIS_SOLO_MAX 3
 #endif
+#ifndef GPIS_GUIDE_SPLIT
+#define GPIS_GUIDE_SPLIT 1
+#endif
+constexpr bool kGuideSplit = GPIS_GUIDE_SPLIT != 0;   // two-way candidate split for clusters of at most 32 lanes
 constexpr int kSoloMaxLanes = GPIS_SOLO_MAX;   // clusters up to this size use the sideways evaluator
 constexpr float kGuidePosEps = 1e-4f;         // bound on |u - w| per axis (cells): measured < 2e-5, see GuideRay
 constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the block's cells an impulse contributes exactly 0
@@ -483,7 +487,8 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
                 if ((int)(threadIdx.x & 63) == src) { fv = v; gp_new = gpx; }
             }
         } else {
-            fv = coop_evaluate_value<SMALLARG>(M, T, lds, in_cluster, pq, coord, gp_new, n_eval);
+            // at most half a wave in the cluster: the idle half helps (two-way candidate split, gpis_fast.hpp)
+            fv = coop_evaluate_value<SMALLARG>(M, T, lds, in_cluster, pq, coord, gp_new, n_eval, kGuideSplit && __popcll(cl_mask) <= 32);
         }
 #ifdef GPIS_FAST_STATS
         for (int ph = X_F0; ph <= X_FINAL; ++ph) {

@@ -258,7 +258,7 @@ GPIS_DEV void guided_march_range(const DevModel &M, const FastTable &T, const Gu
                 if (lane == src) { fv = v; gp_new = gpx; }
             }
         } else {
-            fv = coop_evaluate_value<SMALLARG>(M, T, lds, in_cluster, pq, coord, gp_new, ne);
+            fv = coop_evaluate_value<SMALLARG>(M, T, lds, in_cluster, pq, coord, gp_new, ne, kGuideSplit && __popcll(cl_mask) <= 32);
         }
         n_eval += ne; n_eval_ray += ne;
         if (in_cluster) {

@@ -24,6 +24,7 @@
 #include "gpis_device.hpp"
 #include "gpis_fast.hpp"
 #include "gpis_guide.hpp"
+#include "gpis_guide_range.hpp"
 #include "gpis_wave.hpp"
 
 #pragma clang fp contract(off)
@@ -112,6 +113,15 @@ struct gpis_medium {
     hipEvent_t ws_event[2];
     bool ws_event_set[2];
     // persistent march (gpis_persist.inc): ring of ray counters (one per launch in flight), resident-wave budget
+    // pipelined host path (gpis_sample_distance_host / gpis_transmittance_host): two slots, each with its own stream,
+    // pinned staging and device buffers, so that chunk k's H2D copy overlaps chunk k-1's kernel and chunk k-2's D2H
+    struct HostSlot {
+        hipStream_t stream;
+        hipEvent_t done;
+        char *pin_in, *pin_out, *pin_aux;       // pinned host staging (used when the caller's memory is pageable)
+        char *dev_in, *dev_out, *dev_aux;
+        size_t cap;                             // chunk capacity in records
+    } hs[2];
     unsigned int *d_next;
     unsigned next_slot;
     int persist_waves[8];    // cached occupancy * CUs per kernel instance; 0 = not queried yet
@@ -387,7 +397,10 @@ __global__ void __launch_bounds__(kBlock, GPIS_GENERIC_OCC) k_transmittance(cons
 
 // persistent refilling form of the two kernels above (gpis_persist.inc): a fixed grid of waves pulls rays from
 // a counter.  Q = slots of the per-lane LDS queue between the impulse generator and the kernel body.
-constexpr int kPersistQ = 16;
+#ifndef GPIS_PERSIST_Q
+#define GPIS_PERSIST_Q 16
+#endif
+constexpr int kPersistQ = GPIS_PERSIST_Q;
 constexpr unsigned kPersistSlots = 256;   // ring of ray counters: one per persistent launch in flight
 #ifndef GPIS_PERSIST_OCC
 #define GPIS_PERSIST_OCC 3   // waves per SIMD of the register allocation (LDS: 12.5 KB per wave -> 12 waves per CU)
@@ -1070,6 +1083,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr;
     m->batch_hint = GPIS_ORDER_COHERENT;
     for (int k = 0; k < 2; ++k) { m->ws_event[k] = nullptr; m->ws_event_set[k] = false; }
+    memset(m->hs, 0, sizeof m->hs);
     m->d_next = nullptr; m->next_slot = 0; m->n_cus = prop.multiProcessorCount;
     for (int k = 0; k < 8; ++k) m->persist_waves[k] = 0;
     {   // diagnostic overrides, read here and nowhere else (include/gpis.h: gpis_set_option)
@@ -1085,6 +1099,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         m->opt[GPIS_OPT_PATHS_PRESORT] = !(e2 && e2[0] == '0');
         m->opt[GPIS_OPT_PERSISTENT] = 1;
         if (const char *e = getenv("GPIS_PERSIST")) m->opt[GPIS_OPT_PERSISTENT] = e[0] != '0';
+        m->opt[GPIS_OPT_RANGE_LEN] = 0;       // measured on C1: refill breaks the depth coherence the cooperative evaluator lives on
+        if (const char *e = getenv("GPIS_RANGE_LEN")) { long long v = atoll(e); m->opt[GPIS_OPT_RANGE_LEN] = v <= 0 ? 0 : ((v + 63) / 64) * 64; }
         m->opt[GPIS_OPT_SOLO_MAX] = -1;
         if (const char *e = getenv("GPIS_SOLO_MAX")) m->opt[GPIS_OPT_SOLO_MAX] = atoll(e);
         m->opt[GPIS_OPT_CHUNK_LOG2] = 0;
@@ -1138,6 +1154,17 @@ extern "C" int gpis_destroy(gpis_medium *m)
         if (m->stage[i]) (void)hipFree(m->stage[i]);
     for (int k = 0; k < 2; ++k)
         if (m->ws_event[k]) (void)hipEventDestroy(m->ws_event[k]);
+    for (int k = 0; k < 2; ++k) {
+        gpis_medium::HostSlot &S = m->hs[k];
+        if (S.pin_in) (void)hipHostFree(S.pin_in);
+        if (S.pin_out) (void)hipHostFree(S.pin_out);
+        if (S.pin_aux) (void)hipHostFree(S.pin_aux);
+        if (S.dev_in) (void)hipFree(S.dev_in);
+        if (S.dev_out) (void)hipFree(S.dev_out);
+        if (S.dev_aux) (void)hipFree(S.dev_aux);
+        if (S.done) (void)hipEventDestroy(S.done);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+    }
     if (m->d_model) (void)hipFree(m->d_model);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_next) (void)hipFree(m->d_next);
@@ -1354,6 +1381,21 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
     ProfScope prof(m, 0, s);
     if (m->guide.enabled && wave_march_selected(m, hint))
         return wave_march(m, n, rays, mask, true, out, coeff, nullptr, s);
+    if (m->guide.enabled && m->opt[GPIS_OPT_RANGE_LEN] > 0) {
+        // guided march with in-wave refill (gpis_guide_range.hpp) + one coherent gradient pass
+        RangeArgs a{};
+        a.n = n; a.rays = rays; a.out = out; a.coeff = coeff; a.visible = nullptr; a.mask = mask; a.cnt = m->d_counters; a.guide_cnt = m->d_guide_cnt;
+        a.range_len = (uint32_t)m->opt[GPIS_OPT_RANGE_LEN];
+        const unsigned grid = (unsigned)((n + a.range_len - 1) / a.range_len);
+        const bool small = m->host_model.exp_arg_max < 100.f;
+        if (small) k_guided_range_sd<true><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
+        else k_guided_range_sd<false><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
+        int rc = launch_check("k_guided_range_sd");
+        if (rc) return rc;
+        if (small) k_guided_range_grad<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters);
+        else k_guided_range_grad<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters);
+        return launch_check("k_guided_range_grad");
+    }
     if (m->guide.enabled) {
         if (m->host_model.exp_arg_max < 100.f)
             k_guided_sample_distance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
@@ -1391,6 +1433,15 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
     ProfScope prof(m, 1, s);
     if (m->guide.enabled && wave_march_selected(m, hint))
         return wave_march(m, n, rays, mask, false, nullptr, nullptr, visible, s);
+    if (m->guide.enabled && m->opt[GPIS_OPT_RANGE_LEN] > 0) {
+        RangeArgs a{};
+        a.n = n; a.rays = rays; a.out = nullptr; a.coeff = nullptr; a.visible = visible; a.mask = mask; a.cnt = m->d_counters + 1; a.guide_cnt = m->d_guide_cnt;
+        a.range_len = (uint32_t)m->opt[GPIS_OPT_RANGE_LEN];
+        const unsigned grid = (unsigned)((n + a.range_len - 1) / a.range_len);
+        if (m->host_model.exp_arg_max < 100.f) k_guided_range_tr<true><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
+        else k_guided_range_tr<false><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
+        return launch_check("k_guided_range_tr");
+    }
     if (m->guide.enabled) {
         if (m->host_model.exp_arg_max < 100.f)
             k_guided_transmittance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
@@ -1451,6 +1502,7 @@ extern "C" int gpis_set_option(gpis_medium *m, int option, long long value)
     case GPIS_OPT_PATHS_SORT: case GPIS_OPT_PATHS_PRESORT: case GPIS_OPT_PERSISTENT: CHECK_ARGS(value == 0 || value == 1); break;
     case GPIS_OPT_CHUNK_LOG2: CHECK_ARGS(value == 0 || (value >= 16 && value <= 28)); break;
     case GPIS_OPT_SOLO_MAX: CHECK_ARGS(value >= -1 && value <= 64); break;
+    case GPIS_OPT_RANGE_LEN: CHECK_ARGS(value >= 0 && value <= (1 << 24) && value % 64 == 0); break;
     default: break;
     }
     std::lock_guard<std::mutex> lock(m->mu);
@@ -1523,24 +1575,90 @@ extern "C" int gpis_pcg32_stream_batch(gpis_medium *m, size_t n, const uint64_t 
 }
 
 // ---- host-pointer conveniences -----------------------------------------------------------
+// ---- pipelined host path ------------------------------------------------------------------------------------
+// Records move in chunks through two slots (streams): H2D of chunk k, the march kernel of chunk k-1 and D2H of chunk k-2
+// overlap.  Caller memory that is pinned (gpis_alloc_host, hipHostMalloc, hipHostRegister) is DMA'd directly; pageable
+// memory is staged through the slot's own pinned buffers (one memcpy each way).  A batch of one costs one small H2D,
+// one launch, one D2H and one stream synchronise.
+// records per chunk: 32 MiB of rays in, 24 MiB of results out.  Measured on C1 (guided march, pinned caller memory, 1 Mi rays):
+// 64 Ki-record chunks 74 M segments/s — each chunk's kernel is too small to fill the chip (61 M segments/s for a lone 64 Ki batch
+// against 361 M for 1 Mi) — so chunks are as large as the overlap of three stages allows
+constexpr size_t kHostChunk = 262144;
+constexpr size_t kInRec = sizeof(gpis_ray_in), kOutRecMax = sizeof(gpis_seg_out), kAuxRec = sizeof(gpis_cond_coeff);
+
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+static int host_slot_ensure(gpis_medium *m, int k, size_t cap)
+{
+    gpis_medium::HostSlot &S = m->hs[k];
+    if (!S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    if (!S.done) HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+    if (S.cap >= cap) return GPIS_OK;
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    if (S.pin_in) { (void)hipHostFree(S.pin_in); (void)hipHostFree(S.pin_out); (void)hipHostFree(S.pin_aux); (void)hipFree(S.dev_in); (void)hipFree(S.dev_out); (void)hipFree(S.dev_aux); }
+    S.pin_in = S.pin_out = S.pin_aux = S.dev_in = S.dev_out = S.dev_aux = nullptr; S.cap = 0;
+    HIP_TRY(hipHostMalloc((void **)&S.pin_in, cap * kInRec, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&S.pin_out, cap * kOutRecMax, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&S.pin_aux, cap * kAuxRec, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&S.dev_in, cap * kInRec));
+    HIP_TRY(hipMalloc((void **)&S.dev_out, cap * kOutRecMax));
+    HIP_TRY(hipMalloc((void **)&S.dev_aux, cap * kAuxRec));
+    S.cap = cap;
+    return GPIS_OK;
+}
+// sample == true: sampleDistance (out = gpis_seg_out, aux = gpis_cond_coeff or null); false: transmittance (out = uint8_t)
+static int host_march(gpis_medium *m, bool sample, size_t n, const gpis_ray_in *rays, void *out, gpis_cond_coeff *aux)
+{
+    const size_t out_rec = sample ? sizeof(gpis_seg_out) : 1;
+    const size_t chunk = n < kHostChunk ? n : kHostChunk;
+    const size_t cap = chunk <= 256 ? 256 : (chunk <= 16384 ? 16384 : kHostChunk);   // small batches keep a small slot
+    int st;
+    if ((st = host_slot_ensure(m, 0, cap)) || (n > chunk && (st = host_slot_ensure(m, 1, cap))))
+        return st;
+    const bool in_pinned = is_pinned_host(rays), out_pinned = is_pinned_host(out), aux_pinned = aux && is_pinned_host(aux);
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    struct Pending { size_t first, count; bool live; } pend[2] = {{0, 0, false}, {0, 0, false}};
+    auto retire = [&](int k) -> int {      // chunk in slot k has finished: hand its results to the caller
+        gpis_medium::HostSlot &S = m->hs[k];
+        if (!pend[k].live) return GPIS_OK;
+        HIP_TRY(hipEventSynchronize(S.done));
+        if (!out_pinned) memcpy((char *)out + pend[k].first * out_rec, S.pin_out, pend[k].count * out_rec);
+        if (aux && !aux_pinned) memcpy(aux + pend[k].first, S.pin_aux, pend[k].count * kAuxRec);
+        pend[k].live = false;
+        return GPIS_OK;
+    };
+    for (size_t c = 0; c < n_chunks; ++c) {
+        const int k = (int)(c & 1);
+        gpis_medium::HostSlot &S = m->hs[k];
+        if ((st = retire(k))) return st;
+        const size_t first = c * chunk, count = n - first < chunk ? n - first : chunk;
+        const void *src = rays + first;
+        if (!in_pinned) { memcpy(S.pin_in, src, count * kInRec); src = S.pin_in; }
+        HIP_TRY(hipMemcpyAsync(S.dev_in, src, count * kInRec, hipMemcpyHostToDevice, S.stream));
+        if (sample)
+            st = sample_distance_impl(m, count, (const gpis_ray_in *)S.dev_in, (gpis_seg_out *)S.dev_out, aux ? (gpis_cond_coeff *)S.dev_aux : nullptr, nullptr, S.stream);
+        else
+            st = transmittance_impl(m, count, (const gpis_ray_in *)S.dev_in, (uint8_t *)S.dev_out, nullptr, S.stream);
+        if (st) return st;
+        HIP_TRY(hipMemcpyAsync(out_pinned ? (char *)out + first * out_rec : S.pin_out, S.dev_out, count * out_rec, hipMemcpyDeviceToHost, S.stream));
+        if (aux) HIP_TRY(hipMemcpyAsync(aux_pinned ? (char *)(aux + first) : S.pin_aux, S.dev_aux, count * kAuxRec, hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(hipEventRecord(S.done, S.stream));
+        pend[k] = {first, count, true};
+    }
+    if ((st = retire((int)(n_chunks & 1)))) return st;       // the older chunk first
+    return retire((int)((n_chunks + 1) & 1));
+}
 extern "C" int gpis_sample_distance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff)
 {
     CHECK_ARGS(m && (n == 0 || (rays && out)));
     if (n == 0) return GPIS_OK;
     std::lock_guard<std::mutex> lock(m->mu);
     HIP_TRY(hipSetDevice(m->device));
-    int st;
-    if ((st = ensure_stage(m, 0, n * sizeof(gpis_ray_in))) || (st = ensure_stage(m, 1, n * sizeof(gpis_seg_out))) ||
-        (st = ensure_stage(m, 2, n * sizeof(gpis_cond_coeff))))
-        return st;
-    HIP_TRY(hipMemcpy(m->stage[0], rays, n * sizeof(gpis_ray_in), hipMemcpyHostToDevice));
-    st = sample_distance_impl(m, n, (const gpis_ray_in *)m->stage[0], (gpis_seg_out *)m->stage[1],
-                              coeff ? (gpis_cond_coeff *)m->stage[2] : nullptr, nullptr, nullptr);
-    if (st) return st;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, m->stage[1], n * sizeof(gpis_seg_out), hipMemcpyDeviceToHost));
-    if (coeff) HIP_TRY(hipMemcpy(coeff, m->stage[2], n * sizeof(gpis_cond_coeff), hipMemcpyDeviceToHost));
-    return GPIS_OK;
+    return host_march(m, true, n, rays, out, coeff);
 }
 extern "C" int gpis_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible)
 {
@@ -1548,15 +1666,17 @@ extern "C" int gpis_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_
     if (n == 0) return GPIS_OK;
     std::lock_guard<std::mutex> lock(m->mu);
     HIP_TRY(hipSetDevice(m->device));
-    int st;
-    if ((st = ensure_stage(m, 0, n * sizeof(gpis_ray_in))) || (st = ensure_stage(m, 1, n)))
-        return st;
-    HIP_TRY(hipMemcpy(m->stage[0], rays, n * sizeof(gpis_ray_in), hipMemcpyHostToDevice));
-    st = transmittance_impl(m, n, (const gpis_ray_in *)m->stage[0], (uint8_t *)m->stage[1], nullptr, nullptr);
-    if (st) return st;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(visible, m->stage[1], n, hipMemcpyDeviceToHost));
-    return GPIS_OK;
+    return host_march(m, false, n, rays, visible, nullptr);
+}
+extern "C" void *gpis_alloc_host(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void gpis_free_host(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 extern "C" int gpis_eval_value_host(gpis_medium *m, size_t n, const gpis_query *q, float *value, int32_t *gp_id)
 {
