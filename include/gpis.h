@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GPIS_ABI_VERSION 1
+#define GPIS_ABI_VERSION 2
 
 typedef enum gpis_status {
     GPIS_OK = 0,
@@ -77,8 +77,19 @@ typedef enum gpis_mean_type {
 typedef enum gpis_ramp_type {
     GPIS_RAMP_BOTTOM_TOP = 0,    /* along y */
     GPIS_RAMP_LEFT_RIGHT = 1,    /* along x */
-    GPIS_RAMP_FRONT_BACK = 2     /* along z */
+    GPIS_RAMP_FRONT_BACK = 2,    /* along z */
+    GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT = 3   /* product of a y ramp and an x ramp ("min2".."end2"), GPF.cpp:96-103 */
 } gpis_ramp_type;
+
+/* A procedural field of type "noise" (ProceduralNoise / ProceduralNoiseVec, GPF.hpp:596-776, GPF.cpp:43-138) with one of the
+ * ramp noises; "sandstone" / "rust" are outside the built scope.  Used for the variance field ("var"), and for the mean's
+ * "color" / "emission" (a vector field whose three components are equal for the ramp noises). */
+typedef struct gpis_ramp {
+    int32_t enabled;
+    int32_t type;                    /* gpis_ramp_type */
+    double min, max, start, end;     /* "min", "max", "start", "end"      (defaults 1, 500, 0, 1) */
+    double min2, max2, start2, end2; /* "min2", "max2", "start2", "end2"  (bottom_top_left_right) */
+} gpis_ramp;
 
 typedef struct gpis_mean {
     int32_t type;          /* gpis_mean_type */
@@ -137,6 +148,12 @@ typedef struct gpis_params {
     int32_t has_mean_additional;     /* GaussianProcess::_mean_additional (CSG min), _id_additional = 1 */
     int32_t _pad1;
     gpis_mean mean_additional;
+    /* --- rest of the proc_nonstationary wrapper and of the mean (GPF.cpp:1590-1606, GPF.hpp:803-862) --- */
+    double ls_min2, ls_max2;         /* second ramp of an "ls" field of type bottom_top_left_right */
+    double ls_start2, ls_end2;
+    gpis_ramp var;                   /* "var": getVariance(p) (GPF.cpp:1638-1641); the noise amplitude becomes var(p) * sigma (GPF.cpp:1235-1237) */
+    gpis_ramp mean_color;            /* mean "color":    MediumSample.weight *= color(p) on a hit (GPM.cpp:316) */
+    gpis_ramp mean_emission;         /* mean "emission": MediumSample.emission (GPM.cpp:317) — gpis_mean_color_emission_* */
 } gpis_params;
 
 /*
@@ -288,6 +305,12 @@ int gpis_conditioning_batch(gpis_medium *m, size_t n, const gpis_query *q,
 /* SparseConvolutionNoiseRealization::neePDF / neeGrad (SCN.cpp:652-743). */
 int gpis_nee_pdf_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *pdf, void *stream);
 int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *grad3, void *stream);
+
+/* MeanFunction::color / emission (GPF.hpp:849-857) at n points (xyz triples in DOUBLE, as the reference evaluates them at
+ * ro + rd * t, GPM.cpp:316-317): the factor sampleDistance has already applied to `weight` on a hit, and the value a binding
+ * stores in MediumSample.emission.  color3 / emission3: n xyz triples of float; either may be NULL. */
+int gpis_mean_color_emission_batch(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3, void *stream);
+int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3);
 
 /* Bit-exact primitives (MathUtil.hpp:179-224, UniformSampler.hpp:41-75, BitManip.hpp:47-50):
  * out[i] = xxhash32 of `arity` (1..4) words at words[i*arity..]; and the PCG32 stream

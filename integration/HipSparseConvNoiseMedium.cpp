@@ -78,6 +78,25 @@ void HipSparseConvNoiseMedium::readMean(JsonPtr m, gpis_mean &dst)
     }
 }
 
+// ProceduralNoise / ProceduralNoiseVec::fromJson, GPFunctions.hpp:671-688 / 752-769
+static int noiseType(const std::string &noise)
+{
+    if (noise == "bottom_top") return GPIS_RAMP_BOTTOM_TOP;
+    if (noise == "left_right") return GPIS_RAMP_LEFT_RIGHT;
+    if (noise == "front_back") return GPIS_RAMP_FRONT_BACK;
+    if (noise == "bottom_top_left_right") return GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT;
+    FAIL("hip_sparse_conv_noise: unsupported noise type: '%s'", noise);
+}
+static void readRamp(JsonPtr v, gpis_ramp &r)
+{
+    r.enabled = 1;
+    std::string noise = "bottom_top";
+    v.getField("noise", noise);
+    r.type = noiseType(noise);
+    v.getField("min", r.min); v.getField("max", r.max); v.getField("start", r.start); v.getField("end", r.end);
+    v.getField("min2", r.min2); v.getField("max2", r.max2); v.getField("start2", r.start2); v.getField("end2", r.end2);
+}
+
 // SquaredExponentialCovariance::fromJson, GPFunctions.cpp:654-679; "localScale" GPFunctions.hpp:1481-1484
 void HipSparseConvNoiseMedium::readSquaredExponential(JsonPtr c)
 {
@@ -107,8 +126,11 @@ void HipSparseConvNoiseMedium::readGaussianProcess(JsonPtr gp)
 {
     if (!gp.isObject())
         FAIL("hip_sparse_conv_noise: \"gaussian_process\" must be an inline object");
-    if (auto m = gp["mean"])
+    if (auto m = gp["mean"]) {
         readMean(m, _params.mean);
+        if (auto c = m["color"]) readRamp(c, _params.mean_color);          // MeanFunction::fromJson, GPFunctions.hpp:808-818
+        if (auto e = m["emission"]) readRamp(e, _params.mean_emission);
+    }
     if (auto m = gp["mean_additional"]) {   // GPSampleNodeCSG's second mean (GaussianProcess.cpp:25-39)
         _params.has_mean_additional = 1;
         readMean(m, _params.mean_additional);
@@ -128,15 +150,18 @@ void HipSparseConvNoiseMedium::readGaussianProcess(JsonPtr gp)
             if (auto ls = c["ls"]) {                    // ProceduralNoiseVec, GPFunctions.hpp:759-776
                 std::string noise = "bottom_top";
                 ls.getField("noise", noise);
-                if (noise == "bottom_top") _params.ls_ramp_type = GPIS_RAMP_BOTTOM_TOP;
-                else if (noise == "left_right") _params.ls_ramp_type = GPIS_RAMP_LEFT_RIGHT;
-                else if (noise == "front_back") _params.ls_ramp_type = GPIS_RAMP_FRONT_BACK;
-                else FAIL("hip_sparse_conv_noise: unsupported \"ls\" noise type: '%s'", noise);
+                _params.ls_ramp_type = noiseType(noise);
                 ls.getField("min", _params.ls_min);
                 ls.getField("max", _params.ls_max);
                 ls.getField("start", _params.ls_start);
                 ls.getField("end", _params.ls_end);
+                ls.getField("min2", _params.ls_min2);
+                ls.getField("max2", _params.ls_max2);
+                ls.getField("start2", _params.ls_start2);
+                ls.getField("end2", _params.ls_end2);
             }
+            if (auto var = c["var"])                     // GPFunctions.cpp:1593-1595
+                readRamp(var, _params.var);
         } else {
             FAIL("hip_sparse_conv_noise: unsupported covariance type: '%s'", type);
         }
@@ -315,6 +340,14 @@ bool HipSparseConvNoiseMedium::sampleDistance(PathSampleGenerator &sampler, cons
     if (!_absorptionOnly)
         state.advance();
     sample.p = Vec3f(o.p[0], o.p[1], o.p[2]);
+    if (!o.exited && _params.mean_emission.enabled) {        // sample.emission = emission(ro + rd*t), GaussianProcessMedium.cpp:317
+        Vec3d ip = Vec3d(ray.pos()) + Vec3d(ray.dir()).normalized()*o.t;
+        double p3[3] = {ip.x(), ip.y(), ip.z()};
+        float e[3] = {0.0f, 0.0f, 0.0f};
+        if (gpis_mean_color_emission_host(_handle, 1, p3, nullptr, e) != GPIS_OK)
+            FAIL("gpis_mean_color_emission_host: %s", gpis_last_error());
+        sample.emission = Vec3f(e[0], e[1], e[2]);
+    }
     sample.phase = _phaseFunctions[size_t(state.lastGPId) < _phaseFunctions.size() ? state.lastGPId : 0].get();
     sample.gpId = state.lastGPId;
     sample.ctxt = state.gpContext.get();

@@ -365,17 +365,38 @@ static void mean_weight_space(const oracle_medium *m, v3d p, double *mean, doubl
 
 /* ---- covariance: SE kernel + (optional) procedural non-stationary wrapper ------------ */
 
-/* ProceduralNoiseVec::operator(), GPF.cpp:87-95 (_const = 1): all three components equal */
-static double ls_ramp(const oracle_medium *m, v3d p)
+/* ProceduralNoise::operator() / one component of ProceduralNoiseVec::operator() (all three are equal for these noise
+ * types), GPF.cpp:43-103, with _const = 1 and _scale = 1/(_end - _start), _offset = -_start * _scale (GPF.hpp:684-687) */
+static double ramp_unit(double coord, double start, double end, double mn, double mx)
 {
     const double c = 1.;
-    double mn = m->P.ls_min + c, mx = m->P.ls_max + c;
-    double coord = m->P.ls_ramp_type == GPIS_RAMP_BOTTOM_TOP ? p.y : (m->P.ls_ramp_type == GPIS_RAMP_LEFT_RIGHT ? p.x : p.z);
-    double u = coord * m->ls_scale + m->ls_offset;
+    double scale = 1.0 / (end - start), offset = -start * scale;
+    double lo = mn + c, hi = mx + c;
+    double u = coord * scale + offset;
     u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);                 /* clamp */
-    double a = log(mn * mn), b = log(mx * mx);
+    double a = log(lo * lo), b = log(hi * hi);
     double l = a * (1.0 - u) + b * u;                        /* lerp, MathUtil.hpp:90-94 */
-    return sqrt(exp(l)) - c;
+    return sqrt(exp(l));
+}
+static double ramp_eval(int type, double mn, double mx, double start, double end, double mn2, double mx2, double start2, double end2, v3d p)
+{
+    const double c = 1.;
+    if (type == GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT) {           /* GPF.cpp:96-103: the two factors are narrowed to float */
+        float bottomTop = (float)ramp_unit(p.y, start, end, mn, mx);
+        float leftRight = (float)ramp_unit(p.x, start2, end2, mn2, mx2);
+        return (double)(bottomTop * leftRight) - c * c;
+    }
+    double coord = type == GPIS_RAMP_BOTTOM_TOP ? p.y : (type == GPIS_RAMP_LEFT_RIGHT ? p.x : p.z);
+    return ramp_unit(coord, start, end, mn, mx) - c;
+}
+static double ramp_of(const gpis_ramp *r, v3d p)
+{
+    return ramp_eval(r->type, r->min, r->max, r->start, r->end, r->min2, r->max2, r->start2, r->end2, p);
+}
+static double ls_ramp(const oracle_medium *m, v3d p)
+{
+    const gpis_params *P = &m->P;
+    return ramp_eval(P->ls_ramp_type, P->ls_min, P->ls_max, P->ls_start, P->ls_end, P->ls_min2, P->ls_max2, P->ls_start2, P->ls_end2, p);
 }
 /* sparseConvNoiseLateralScale: GPF.cpp:607-609 / 1219-1221 → getKernelScale GPF.cpp:1729-1735 */
 static float cov_lateral_scale(const oracle_medium *m, v3f p)
@@ -396,13 +417,14 @@ static float cov_ns_scale(const oracle_medium *m, v3f p)
 }
 /* worldSamplingSpatialScale: GPF.hpp:1494 / GPF.cpp:1231-1233 */
 static float cov_world_sampling_scale(const oracle_medium *m) { return m->P.nonstationary ? cov_max_lateral_scale(m) : 1.f; }
-/* sparseConvNoiseAmplitude: GPF.cpp:611-613,711 / 1235-1237 (getVariance = 1 without a "var" field) */
+/* sparseConvNoiseAmplitude: GPF.cpp:611-613,711 (stationary) / 1235-1237: getVariance(Vec3d(p)) * sigma, with
+ * getVariance = the "var" field or 1 (GPF.cpp:1638-1641) */
 static float cov_amplitude(const oracle_medium *m, v3f p)
 {
-    (void)p;
     if (!m->P.nonstationary)
         return m->P.sigma;
-    return (float)(1.0 * m->P.sigma);
+    double var = m->P.var.enabled ? ramp_of(&m->P.var, v3d_of(p)) : 1.0;
+    return (float)(var * m->P.sigma);
 }
 /* SquaredExponentialCovariance::splattingKernelRadius, GPF.cpp:696-709 */
 static float se_kernel_radius(const oracle_medium *m, int isIdentity, float localScale)
@@ -1420,8 +1442,11 @@ static void sample_distance_one(const oracle_medium *m, oracle_counters *cnt, co
                 out->last_val = state.last_val; out->gp_id = state.last_gp_id; out->ok = 0;
                 goto done;
             }
-            out->weight[0] = out->weight[1] = out->weight[2] = 1.f;             /* color() = 1 */
-            out->continued_weight[0] = out->continued_weight[1] = out->continued_weight[2] = 1.f;
+            /* sample.weight = sample.continuedWeight = vec_conv<Vec3f>(_gp->color(ro + rd * t)), GPM.cpp:316; MeanFunction::color
+             * is 1 without a "color" field (GPF.hpp:849-852) */
+            float col = m->P.mean_color.enabled ? (float)ramp_of(&m->P.mean_color, ray_at(ro, rd, t)) : 1.f;
+            out->weight[0] = out->weight[1] = out->weight[2] = col;
+            out->continued_weight[0] = out->continued_weight[1] = out->continued_weight[2] = col;
         } else {
             v3f g = evaluate_gradient(&noise, v3f_of(ray_at(ro, rd, t)), (float)t, dir, state.info);
             aniso = v3d_of(g);
@@ -1517,6 +1542,14 @@ void oracle_default_params(gpis_params *p)
     p->aniso_mtx[0] = p->aniso_mtx[4] = p->aniso_mtx[8] = 1.f;
     p->local_scale = 3.0f;                                                           /* GPF.hpp:1729 */
     p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;              /* GPF.hpp:694-695 */
+    p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          /* GPF.hpp:697-698 */
+    {
+        gpis_ramp *ramps[3] = {&p->var, &p->mean_color, &p->mean_emission};
+        for (int i = 0; i < 3; ++i) {
+            ramps[i]->min = 1.; ramps[i]->max = 500.; ramps[i]->start = 0.; ramps[i]->end = 1.;
+            ramps[i]->min2 = 1.; ramps[i]->max2 = 500.; ramps[i]->start2 = 0.; ramps[i]->end2 = 1.;
+        }
+    }
     p->mean.type = GPIS_MEAN_SPHERICAL; p->mean.radius = 1.f;                        /* SCNM.cpp:19 */
     p->mean.scale = 1.f; p->mean.min = -FLT_MAX; p->mean.dir[0] = 1.;
     p->mean_additional = p->mean;
@@ -1531,6 +1564,11 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
     if (params->correlation_context < 0 || params->correlation_context > 3) return fail("invalid correlation context");
     if (params->scheme_1d < 0 || params->scheme_1d > 2) return fail("invalid sparse conv sampling scheme");
     if (!(params->impulse_density >= 0.f)) return fail("invalid impulse_density");
+    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > 3)) return fail("invalid ls ramp type");
+    if ((params->var.enabled && (params->var.type < 0 || params->var.type > 3)) || (params->mean_color.enabled && (params->mean_color.type < 0 || params->mean_color.type > 3)) ||
+        (params->mean_emission.enabled && (params->mean_emission.type < 0 || params->mean_emission.type > 3)))
+        return fail("invalid procedural noise type");
+    if (params->var.enabled && !params->nonstationary) return fail("a var field needs the proc_nonstationary wrapper");
     oracle_medium *m = (oracle_medium *)calloc(1, sizeof *m);
     if (!m) return GPIS_ERR_DEVICE;
     m->P = *params;
@@ -1571,7 +1609,12 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
     /* ramp, GPF.hpp:773-774 and maxVal GPF.cpp:124-130 */
     m->ls_scale = 1.0 / (P->ls_end - P->ls_start);
     m->ls_offset = -P->ls_start * m->ls_scale;
-    { double mx = P->ls_max > P->ls_min ? P->ls_max : P->ls_min; m->ls_maxval = (float)mx; }
+    {   /* ProceduralNoiseVec::maxVal, GPF.cpp:124-138 */
+        double mx = P->ls_max > P->ls_min ? P->ls_max : P->ls_min;
+        if (P->ls_ramp_type == GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT)
+            mx = mx * (P->ls_max2 > P->ls_min2 ? P->ls_max2 : P->ls_min2);
+        m->ls_maxval = (float)mx;
+    }
     /* prepareForRender, GPM.cpp:152-158 */
     int all_zero = 1;
     for (int c = 0; c < 3; ++c) {
@@ -1792,6 +1835,24 @@ int oracle_nee_grad_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, f
     if (!m || (n && (!q || !grad3))) return fail("null argument");
     nee_ctx c = {q, NULL, grad3};
     parallel_for(m, n, np_range, &c);
+    return GPIS_OK;
+}
+
+/* MeanFunction::color / emission, GPF.hpp:849-857 (1 / 0 without the field; ramp noises have three equal components) */
+int oracle_mean_color_emission(oracle_medium *m, size_t n, const double *p3, float *color3, float *emission3)
+{
+    if (!m || (n && !p3)) return fail("null argument");
+    for (size_t i = 0; i < n; ++i) {
+        v3d p = {p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]};
+        if (color3) {
+            float c = m->P.mean_color.enabled ? (float)ramp_of(&m->P.mean_color, p) : 1.f;
+            color3[3 * i] = color3[3 * i + 1] = color3[3 * i + 2] = c;
+        }
+        if (emission3) {
+            float e = m->P.mean_emission.enabled ? (float)ramp_of(&m->P.mean_emission, p) : 0.f;
+            emission3[3 * i] = emission3[3 * i + 1] = emission3[3 * i + 2] = e;
+        }
+    }
     return GPIS_OK;
 }
 

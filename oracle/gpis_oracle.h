@@ -47,6 +47,7 @@ int oracle_conditioning_batch(oracle_medium *m, size_t n, const gpis_query *q, c
 int oracle_nee_pdf_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, float *pdf);
 int oracle_nee_grad_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, float *grad3);
 
+int oracle_mean_color_emission(oracle_medium *m, size_t n, const double *p3, float *color3, float *emission3);
 int oracle_xxhash32_batch(size_t n, int arity, const uint32_t *words, uint32_t *out);
 int oracle_pcg32_stream_batch(size_t n, const uint64_t *state, uint32_t count, uint32_t *out);
 

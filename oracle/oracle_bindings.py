@@ -55,13 +55,14 @@ class Oracle:
         L.oracle_conditioning_batch.argtypes = [_vp, _sz, _vp, _vp, _vp, _vp]
         L.oracle_nee_pdf_batch.argtypes = [_vp, _sz, _vp, _vp]
         L.oracle_nee_grad_batch.argtypes = [_vp, _sz, _vp, _vp]
+        L.oracle_mean_color_emission.argtypes = [_vp, _sz, _vp, _vp, _vp]
         L.oracle_get_counters.argtypes = [_vp, _vp, _vp]
         L.oracle_reset_counters.argtypes = [_vp]
         L.oracle_render_scene_s.argtypes = [_vp, _vp, _vp, _vp]
         L.oracle_scene_s_primary.argtypes = [_vp, _u32, _u32, _u32, _vp, _vp]
         L.oracle_render_scene_s_paths.argtypes = [_vp, _vp, _i32, _f32, _vp]
         L.oracle_render_scene_s_nee.argtypes = [_vp, _vp, _vp, _vp]
-        self.params = np.array(params, dtype=PARAMS)
+        self.params = _T.as_params(params)
         h = _vp()
         st = L.oracle_create(_p(self.params), ctypes.byref(h))
         if st != 0:
@@ -130,6 +131,13 @@ class Oracle:
         out = np.zeros((q.shape[0], 3), dtype=np.float32)
         assert self.lib.oracle_nee_grad_batch(self.h, q.shape[0], _p(q), _p(out)) == 0
         return out
+
+    def mean_color_emission(self, points):
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        col = np.zeros((p.shape[0], 3), dtype=np.float32)
+        emi = np.zeros((p.shape[0], 3), dtype=np.float32)
+        assert self.lib.oracle_mean_color_emission(self.h, p.shape[0], _p(p), _p(col), _p(emi)) == 0
+        return col, emi
 
     def counters(self):
         e, s = _u64(), _u64()

@@ -8,7 +8,7 @@ library is missing or no GPU is present, the calls fail loudly.
 """
 from .bindings import (  # noqa: F401
     GpisLib, Medium, load_library, library_path,
-    PARAMS, MEAN, RAY_IN, SEG_OUT, COND_COEFF, QUERY, NEE_QUERY, DERIVED, SCENE_S, SURFACE_S, default_surface_s, default_scene_s,
-    default_params, params_for_config, CTX, SCHEME, MEAN_TYPE,
+    PARAMS, MEAN, RAMP, RAY_IN, SEG_OUT, COND_COEFF, QUERY, NEE_QUERY, DERIVED, SCENE_S, SURFACE_S, default_surface_s, default_scene_s,
+    default_params, params_for_config, as_params, CTX, SCHEME, MEAN_TYPE,
 )
 from . import dist  # noqa: F401

@@ -27,6 +27,12 @@ MEAN = np.dtype([
     ("center", "<f8", 3), ("dir", "<f8", 3),
 ], align=True)
 
+RAMP = np.dtype([
+    ("enabled", "<i4"), ("type", "<i4"),
+    ("min", "<f8"), ("max", "<f8"), ("start", "<f8"), ("end", "<f8"),
+    ("min2", "<f8"), ("max2", "<f8"), ("start2", "<f8"), ("end2", "<f8"),
+], align=True)
+
 PARAMS = np.dtype([
     ("abi_version", "<u4"),
     ("step_size", "<f4"), ("min_step", "<u4"), ("seed", "<u4"), ("impulse_density", "<f4"),
@@ -40,6 +46,8 @@ PARAMS = np.dtype([
     ("nonstationary", "<i4"), ("multi_resolution_grid", "<i4"), ("ls_ramp_type", "<i4"), ("_pad0", "<i4"),
     ("ls_min", "<f8"), ("ls_max", "<f8"), ("ls_start", "<f8"), ("ls_end", "<f8"),
     ("mean", MEAN), ("has_mean_additional", "<i4"), ("_pad1", "<i4"), ("mean_additional", MEAN),
+    ("ls_min2", "<f8"), ("ls_max2", "<f8"), ("ls_start2", "<f8"), ("ls_end2", "<f8"),
+    ("var", RAMP), ("mean_color", RAMP), ("mean_emission", RAMP),
 ], align=True)
 
 RAY_IN = np.dtype([
@@ -117,7 +125,7 @@ _EXPECTED_SIZES = {
     "gpis_params": PARAMS.itemsize, "gpis_mean": MEAN.itemsize, "gpis_ray_in": RAY_IN.itemsize,
     "gpis_seg_out": SEG_OUT.itemsize, "gpis_cond_coeff": COND_COEFF.itemsize, "gpis_query": QUERY.itemsize,
     "gpis_nee_query": NEE_QUERY.itemsize, "gpis_derived": DERIVED.itemsize, "gpis_scene_s": SCENE_S.itemsize,
-    "gpis_surface_s": SURFACE_S.itemsize,
+    "gpis_surface_s": SURFACE_S.itemsize, "gpis_ramp": RAMP.itemsize,
 }
 assert RAY_IN.itemsize == 128 and SEG_OUT.itemsize == 96 and COND_COEFF.itemsize == 32
 assert QUERY.itemsize == 96 and NEE_QUERY.itemsize == 96
@@ -126,7 +134,7 @@ assert QUERY.itemsize == 96 and NEE_QUERY.itemsize == 96
 def default_params():
     """Reference defaults (SCNM.cpp:17-34, GPM.cpp:86-95, GPF.hpp:1729,1784) as a PARAMS record."""
     p = np.zeros((), dtype=PARAMS)
-    p["abi_version"] = 1
+    p["abi_version"] = 2
     p["step_size"] = 0.01
     p["min_step"] = 8
     p["impulse_density"] = 3.0
@@ -139,12 +147,35 @@ def default_params():
     p["aniso_mtx"] = np.eye(3, dtype=np.float32).ravel()
     p["local_scale"] = 3.0
     p["ls_min"], p["ls_max"], p["ls_start"], p["ls_end"] = 1.0, 500.0, 0.0, 1.0
+    p["ls_min2"], p["ls_max2"], p["ls_start2"], p["ls_end2"] = 1.0, 500.0, 0.0, 1.0
+    for key in ("var", "mean_color", "mean_emission"):
+        p[key]["min"], p[key]["max"], p[key]["start"], p[key]["end"] = 1.0, 500.0, 0.0, 1.0
+        p[key]["min2"], p[key]["max2"], p[key]["start2"], p[key]["end2"] = 1.0, 500.0, 0.0, 1.0
     for key in ("mean", "mean_additional"):
         p[key]["type"] = MEAN_TYPE.SPHERICAL
         p[key]["radius"] = 1.0
         p[key]["scale"] = 1.0
         p[key]["min"] = -np.finfo(np.float32).max
         p[key]["dir"] = (1.0, 0.0, 0.0)
+    return p
+
+
+def as_params(rec):
+    """A parameter record of an older ABI (the golden fixtures of round 1 hold 352-byte records) widened to the current
+    layout: the fields it has are copied, the new ones keep the reference's defaults."""
+    rec = np.asarray(rec)
+    if rec.dtype == PARAMS:
+        return np.array(rec, dtype=PARAMS)
+    p = default_params()
+
+    def copy(dst, src):
+        for name in src.dtype.names:
+            if name in dst.dtype.names and name != "abi_version":
+                if src.dtype[name].names:
+                    copy(dst[name], src[name])
+                else:
+                    dst[name] = src[name]
+    copy(p, rec)
     return p
 
 
@@ -218,7 +249,7 @@ class GpisLib:
         "gpis_create", "gpis_destroy", "gpis_get_derived", "gpis_last_error", "gpis_default_params",
         "gpis_sample_distance_batch", "gpis_transmittance_batch", "gpis_eval_value_batch",
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
-        "gpis_xxhash32_batch", "gpis_pcg32_stream_batch",
+        "gpis_xxhash32_batch", "gpis_pcg32_stream_batch", "gpis_mean_color_emission_batch", "gpis_mean_color_emission_host",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
@@ -257,6 +288,8 @@ class GpisLib:
         L.gpis_conditioning_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp]
         L.gpis_nee_pdf_batch.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_nee_grad_batch.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_mean_color_emission_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+        L.gpis_mean_color_emission_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_xxhash32_batch.argtypes = [vp, sz, i32, vp, vp, vp]
         L.gpis_pcg32_stream_batch.argtypes = [vp, sz, vp, u32, vp, vp]
         L.gpis_sample_distance_host.argtypes = [vp, sz, vp, vp, vp]
@@ -316,7 +349,7 @@ class Medium:
 
     def __init__(self, params, device=0, lib=None):
         self.L = lib or load_library()
-        self.params = np.array(params, dtype=PARAMS)
+        self.params = as_params(params)
         h = ctypes.c_void_p()
         st = self.L.lib.gpis_create(_ptr(self.params), int(device), ctypes.byref(h))
         self.L.check(st, "gpis_create")
@@ -353,6 +386,14 @@ class Medium:
         self.L.check(self.L.lib.gpis_transmittance_host(self.h, rays.shape[0], _ptr(rays), _ptr(vis)),
                      "gpis_transmittance_host")
         return vis
+
+    def mean_color_emission(self, points):
+        """(color, emission) of the mean at double-precision points (n, 3)"""
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        col = np.zeros((p.shape[0], 3), dtype=np.float32)
+        emi = np.zeros((p.shape[0], 3), dtype=np.float32)
+        self.L.check(self.L.lib.gpis_mean_color_emission_host(self.h, p.shape[0], _ptr(p), _ptr(col), _ptr(emi)), "gpis_mean_color_emission_host")
+        return col, emi
 
     def eval_value(self, q):
         q = np.ascontiguousarray(q, dtype=QUERY)

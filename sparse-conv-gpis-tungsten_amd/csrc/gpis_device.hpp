@@ -32,6 +32,19 @@ constexpr int kLevelMax = 24;
 constexpr int kLevels = kLevelMax - kLevelMin + 1;
 
 // Host-precomputed, device-resident constants of one medium (uniform → scalar loads).
+// ProceduralNoise / ProceduralNoiseVec of type "noise" with a ramp (GPF.cpp:43-138): logs from the host libm
+struct DevRamp {
+    int32_t enabled, type;
+    double scale, offset, log_min2, log_max2;        // first ramp: clamp(coord * scale + offset), lerp of log(min^2), log(max^2)
+    double scale2, offset2, log2_min2, log2_max2;    // second ramp (bottom_top_left_right)
+};
+GPIS_DEV double ramp_unit(double coord, double scale, double offset, double la, double lb)
+{
+    double u = coord * scale + offset;
+    u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+    double l = la * (1.0 - u) + lb * u;
+    return sqrt(exp(l));
+}
 struct DevModel {
     // flags (SCNM.cpp:57-73, SCN.cpp:21-30)
     int32_t single_realization, iso3d, sampling_1d, correlation_xy, ctx;
@@ -56,6 +69,9 @@ struct DevModel {
     int32_t ls_ramp_type;
     float ls_maxval;
     double ls_min, ls_max, ls_scale, ls_offset, ls_log_min2, ls_log_max2;
+    DevRamp ls;                   // the same "ls" field in the general form (bottom_top_left_right needs the second ramp)
+    DevRamp var, color, emission; // "var" (GPF.cpp:1638-1641), mean "color" / "emission" (GPF.hpp:849-857)
+    float sigma_raw;              // the stationary kernel's sigma (sparseConvNoiseAmplitude() of GPF.cpp:711)
     // multi-resolution level tables (host libm: powf / logf), index level - kLevelMin
     float level_scale[kLevels];           // powf(2.5, level)
     int32_t level_addseed[kLevels];       // (int)floorf(logf(level_scale)/logf(2.5))
@@ -190,6 +206,17 @@ struct V3d { double x, y, z; };
 struct V4 { float v, gx, gy, gz; };
 
 GPIS_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+// ProceduralNoise::operator() / ProceduralNoiseVec::operator() (one component), GPF.cpp:43-103, _const = 1
+GPIS_DEV double ramp_eval(const DevRamp &R, V3d p)
+{
+    if (R.type == GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT) {
+        float bottomTop = (float)ramp_unit(p.y, R.scale, R.offset, R.log_min2, R.log_max2);
+        float leftRight = (float)ramp_unit(p.x, R.scale2, R.offset2, R.log2_min2, R.log2_max2);
+        return (double)(bottomTop * leftRight) - 1.0 * 1.0;
+    }
+    double coord = R.type == GPIS_RAMP_BOTTOM_TOP ? p.y : (R.type == GPIS_RAMP_LEFT_RIGHT ? p.x : p.z);
+    return ramp_unit(coord, R.scale, R.offset, R.log_min2, R.log_max2) - 1.0;
+}
 GPIS_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 GPIS_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 GPIS_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }

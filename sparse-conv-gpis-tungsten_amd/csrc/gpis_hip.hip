@@ -198,6 +198,7 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
     M.step_size = P.step_size;
     M.impulse_density = P.impulse_density;
     M.sigma = M.nonstationary ? (float)(1.0 * (double)P.sigma) : P.sigma;
+    M.sigma_raw = P.sigma;
 
     // SquaredExponentialCovariance::fromJson
     float l_conv = P.length_scale * sqrtf(2.f) / 2;
@@ -246,6 +247,26 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
     M.ls_offset = -P.ls_start * M.ls_scale;
     { double mn = P.ls_min + 1., mx = P.ls_max + 1.; M.ls_log_min2 = log(mn * mn); M.ls_log_max2 = log(mx * mx); }
     M.ls_maxval = (float)(P.ls_max > P.ls_min ? P.ls_max : P.ls_min);
+    // the procedural fields in their general form (host libm for the logs, as the reference computes them per call)
+    auto make_ramp = [](int enabled, int type, double mn, double mx, double st, double en, double mn2, double mx2, double st2, double en2) {
+        DevRamp R;
+        memset(&R, 0, sizeof R);
+        R.enabled = enabled; R.type = type;
+        R.scale = 1.0 / (en - st); R.offset = -st * R.scale;
+        R.scale2 = 1.0 / (en2 - st2); R.offset2 = -st2 * R.scale2;
+        const double a = mn + 1., b = mx + 1., a2 = mn2 + 1., b2 = mx2 + 1.;
+        R.log_min2 = log(a * a); R.log_max2 = log(b * b);
+        R.log2_min2 = log(a2 * a2); R.log2_max2 = log(b2 * b2);
+        return R;
+    };
+    M.ls = make_ramp(M.nonstationary, P.ls_ramp_type, P.ls_min, P.ls_max, P.ls_start, P.ls_end, P.ls_min2, P.ls_max2, P.ls_start2, P.ls_end2);
+    M.var = make_ramp(P.var.enabled != 0, P.var.type, P.var.min, P.var.max, P.var.start, P.var.end, P.var.min2, P.var.max2, P.var.start2, P.var.end2);
+    M.color = make_ramp(P.mean_color.enabled != 0, P.mean_color.type, P.mean_color.min, P.mean_color.max, P.mean_color.start, P.mean_color.end,
+                        P.mean_color.min2, P.mean_color.max2, P.mean_color.start2, P.mean_color.end2);
+    M.emission = make_ramp(P.mean_emission.enabled != 0, P.mean_emission.type, P.mean_emission.min, P.mean_emission.max, P.mean_emission.start, P.mean_emission.end,
+                           P.mean_emission.min2, P.mean_emission.max2, P.mean_emission.start2, P.mean_emission.end2);
+    if (P.ls_ramp_type == GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT)      // ProceduralNoiseVec::maxVal, GPF.cpp:124-138
+        M.ls_maxval = (float)((P.ls_max > P.ls_min ? P.ls_max : P.ls_min) * (P.ls_max2 > P.ls_min2 ? P.ls_max2 : P.ls_min2));
     const float base = 2.5f;
     M.log_base = logf(base);
     for (int l = kLevelMin; l <= kLevelMax; ++l) {
@@ -475,6 +496,23 @@ __global__ void __launch_bounds__(kBlock) k_nee(const DevModel *__restrict__ Mp,
         }
     }
     flush_counters(cnt, r.n_eval, 0);
+}
+// MeanFunction::color / emission at double-precision points (GPF.hpp:849-857; ramp noises: three equal components)
+__global__ void __launch_bounds__(256) k_mean_color_emission(const DevModel *__restrict__ Mp, size_t n, const double *__restrict__ p3,
+                                                             float *__restrict__ color3, float *__restrict__ emission3)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevModel &M = *Mp;
+    const V3d p{p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]};
+    if (color3) {
+        const float c = M.color.enabled ? (float)ramp_eval(M.color, p) : 1.f;
+        color3[3 * i] = c; color3[3 * i + 1] = c; color3[3 * i + 2] = c;
+    }
+    if (emission3) {
+        const float e = M.emission.enabled ? (float)ramp_eval(M.emission, p) : 0.f;
+        emission3[3 * i] = e; emission3[3 * i + 1] = e; emission3[3 * i + 2] = e;
+    }
 }
 __global__ void k_xxhash32(size_t n, int arity, const uint32_t *__restrict__ w, uint32_t *__restrict__ out)
 {
@@ -1030,9 +1068,9 @@ extern "C" const char *gpis_abi_sizes(void)
     static char buf[512];
     snprintf(buf, sizeof buf,
              "gpis_params=%zu,gpis_mean=%zu,gpis_ray_in=%zu,gpis_seg_out=%zu,gpis_cond_coeff=%zu,gpis_query=%zu,"
-             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu,gpis_surface_s=%zu",
+             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu,gpis_surface_s=%zu,gpis_ramp=%zu",
              sizeof(gpis_params), sizeof(gpis_mean), sizeof(gpis_ray_in), sizeof(gpis_seg_out), sizeof(gpis_cond_coeff),
-             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s), sizeof(gpis_surface_s));
+             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s), sizeof(gpis_surface_s), sizeof(gpis_ramp));
     return buf;
 }
 
@@ -1050,6 +1088,9 @@ extern "C" void gpis_default_params(gpis_params *p)
     p->aniso_mtx[0] = p->aniso_mtx[4] = p->aniso_mtx[8] = 1.f;
     p->local_scale = 3.0f;
     p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;
+    p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          // GPF.hpp:694-699
+    gpis_ramp *ramps[3] = {&p->var, &p->mean_color, &p->mean_emission};
+    for (gpis_ramp *r : ramps) { r->min = 1.; r->max = 500.; r->start = 0.; r->end = 1.; r->min2 = 1.; r->max2 = 500.; r->start2 = 0.; r->end2 = 1.; }
     p->mean.type = GPIS_MEAN_SPHERICAL; p->mean.radius = 1.f;
     p->mean.scale = 1.f; p->mean.min = -FLT_MAX; p->mean.dir[0] = 1.;
     p->mean_additional = p->mean;
@@ -1065,7 +1106,13 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     if (!(params->impulse_density >= 0.f) || params->impulse_density > 4096.f) return set_err(GPIS_ERR_INVALID_ARG, "impulse_density out of range");
     if (params->mean.type < 0 || params->mean.type > 2 || (params->has_mean_additional && (params->mean_additional.type < 0 || params->mean_additional.type > 2)))
         return set_err(GPIS_ERR_INVALID_ARG, "invalid mean type");
-    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > 2)) return set_err(GPIS_ERR_INVALID_ARG, "invalid ls ramp type");
+    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > 3)) return set_err(GPIS_ERR_INVALID_ARG, "invalid ls ramp type");
+    {
+        const gpis_ramp *ramps[3] = {&params->var, &params->mean_color, &params->mean_emission};
+        for (const gpis_ramp *r : ramps)
+            if (r->enabled && (r->type < 0 || r->type > 3)) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type (sandstone / rust are outside the built scope)");
+        if (params->var.enabled && !params->nonstationary) return set_err(GPIS_ERR_INVALID_ARG, "a \"var\" field needs the proc_nonstationary wrapper");
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return set_err(GPIS_ERR_NO_DEVICE, "gpis_create: no HIP device visible (this library has no CPU fallback)");
@@ -1556,6 +1603,31 @@ extern "C" int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_quer
     HIP_TRY(hipSetDevice(m->device));
     k_nee<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, nullptr, grad3, m->d_counters);
     return launch_check("k_nee");
+}
+extern "C" int gpis_mean_color_emission_batch(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || p3));
+    if (n == 0 || (!color3 && !emission3)) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    k_mean_color_emission<<<grid_of(n, 256), 256, 0, (hipStream_t)stream>>>(m->d_model, n, p3, color3, emission3);
+    return launch_check("k_mean_color_emission");
+}
+extern "C" int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3)
+{
+    CHECK_ARGS(m && (n == 0 || p3));
+    if (n == 0 || (!color3 && !emission3)) return GPIS_OK;
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    int st;
+    if ((st = ensure_stage(m, 0, 3 * n * sizeof(double))) || (st = ensure_stage(m, 1, 3 * n * sizeof(float))) || (st = ensure_stage(m, 2, 3 * n * sizeof(float))))
+        return st;
+    HIP_TRY(hipMemcpy(m->stage[0], p3, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    st = gpis_mean_color_emission_batch(m, n, (const double *)m->stage[0], color3 ? (float *)m->stage[1] : nullptr, emission3 ? (float *)m->stage[2] : nullptr, nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    if (color3) HIP_TRY(hipMemcpy(color3, m->stage[1], 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (emission3) HIP_TRY(hipMemcpy(emission3, m->stage[2], 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    return GPIS_OK;
 }
 extern "C" int gpis_xxhash32_batch(gpis_medium *m, size_t n, int arity, const uint32_t *words, uint32_t *out, void *stream)
 {

@@ -122,6 +122,25 @@ void getVec3d(const JValue &o, const char *key, double *dst)
     }
 }
 
+int noiseType(const std::string &noise)            // ProceduralNoise(Vec)::stringToNoiseType, GPF.hpp:644-661
+{
+    if (noise == "bottom_top") return GPIS_RAMP_BOTTOM_TOP;
+    if (noise == "left_right") return GPIS_RAMP_LEFT_RIGHT;
+    if (noise == "front_back") return GPIS_RAMP_FRONT_BACK;
+    if (noise == "bottom_top_left_right") return GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT;
+    if (noise == "sandstone" || noise == "rust") throw std::runtime_error("noise type '" + noise + "' is outside the built scope");
+    throw std::runtime_error("Invalid noise typ function: '" + noise + "'");
+}
+void readRamp(const JValue &v, gpis_ramp &r)         // ProceduralNoise::fromJson, GPF.hpp:671-688
+{
+    r.enabled = 1;
+    std::string noise = "bottom_top";
+    if (const JValue *n = v.get("noise")) noise = n->str;
+    r.type = noiseType(noise);
+    getNum(v, "min", r.min); getNum(v, "max", r.max); getNum(v, "start", r.start); getNum(v, "end", r.end);
+    getNum(v, "min2", r.min2); getNum(v, "max2", r.max2); getNum(v, "start2", r.start2); getNum(v, "end2", r.end2);
+}
+
 void readMean(const JValue &m, gpis_mean &dst)
 {
     std::string type = "spherical";
@@ -208,7 +227,11 @@ void HipSparseConvNoiseMedium::fromJson(const std::string &json)
     getNum(v, "surf_vol_phase_separate", p.surf_vol_phase_separate);
     getNum(v, "surf_vol_phase_amp_thresh", p.surf_vol_phase_amp_thresh);
     if (const JValue *gp = v.get("gaussian_process")) {
-        if (const JValue *m = gp->get("mean")) readMean(*m, p.mean);
+        if (const JValue *m = gp->get("mean")) {
+            readMean(*m, p.mean);
+            if (const JValue *c = m->get("color")) readRamp(*c, p.mean_color);        // MeanFunction::fromJson, GPF.hpp:808-818
+            if (const JValue *e = m->get("emission")) readRamp(*e, p.mean_emission);
+        }
         if (const JValue *m = gp->get("mean_additional")) {
             p.has_mean_additional = 1;
             readMean(*m, p.mean_additional);
@@ -225,17 +248,19 @@ void HipSparseConvNoiseMedium::fromJson(const std::string &json)
                 if (const JValue *ls = c->get("ls")) {            // ProceduralNoiseVec, GPF.hpp:759-776
                     std::string noise = "bottom_top";
                     if (const JValue *n = ls->get("noise")) noise = n->str;
-                    if (noise == "bottom_top") p.ls_ramp_type = GPIS_RAMP_BOTTOM_TOP;
-                    else if (noise == "left_right") p.ls_ramp_type = GPIS_RAMP_LEFT_RIGHT;
-                    else if (noise == "front_back") p.ls_ramp_type = GPIS_RAMP_FRONT_BACK;
-                    else throw std::runtime_error("Unsupported ls noise type: '" + noise + "'");
+                    p.ls_ramp_type = noiseType(noise);
                     getNum(*ls, "min", p.ls_min);
                     getNum(*ls, "max", p.ls_max);
                     getNum(*ls, "start", p.ls_start);
                     getNum(*ls, "end", p.ls_end);
+                    getNum(*ls, "min2", p.ls_min2);
+                    getNum(*ls, "max2", p.ls_max2);
+                    getNum(*ls, "start2", p.ls_start2);
+                    getNum(*ls, "end2", p.ls_end2);
                 }
-                if (c->get("var") || c->get("aniso"))
-                    throw std::runtime_error("proc_nonstationary 'var' / 'aniso' fields are outside the built scope");
+                if (const JValue *var = c->get("var")) readRamp(*var, p.var);          // GPF.cpp:1593-1595
+                if (c->get("aniso"))
+                    throw std::runtime_error("proc_nonstationary 'aniso' field is outside the built scope");
             } else {
                 throw std::runtime_error("Unsupported covariance type: '" + type + "'");
             }
@@ -322,6 +347,13 @@ void HipSparseConvNoiseMedium::applyResult(const Ray &ray, const gpis_seg_out &o
     sample.pdf = 1.0f;
     sample.p.x = o.p[0]; sample.p.y = o.p[1]; sample.p.z = o.p[2];
     sample.sparseConv1DSamplingScheme = (SparseConv1DSamplingScheme)o.scheme;
+    if (!o.exited && _params.mean_emission.enabled) {          // sample.emission = emission(ro + rd*t), GPM.cpp:317
+        double dl = std::sqrt((double)ray.dir.x * ray.dir.x + (double)ray.dir.y * ray.dir.y + (double)ray.dir.z * ray.dir.z);
+        double p3[3] = {ray.pos.x + ray.dir.x / dl * o.t, ray.pos.y + ray.dir.y / dl * o.t, ray.pos.z + ray.dir.z / dl * o.t};
+        float e[3] = {0, 0, 0};
+        if (gpis_mean_color_emission_host(_handle, 1, p3, nullptr, e) != GPIS_OK) throw std::runtime_error(std::string("gpis_mean_color_emission_host: ") + gpis_last_error());
+        sample.emission.x = e[0]; sample.emission.y = e[1]; sample.emission.z = e[2];
+    }
     const bool absorption = _sigmaS[0] == 0.f && _sigmaS[1] == 0.f && _sigmaS[2] == 0.f;
     if (!absorption)                           // the absorption-only branch (GPM.cpp:250-258) does not advance;
         state.advance();

@@ -66,6 +66,19 @@ static void test_parse()
         "multiResolutionGrid": true, "cov": {"type": "squared_exponential", "sigma": 0.1, "lengthScale": 0.05},
         "ls": {"type": "noise", "noise": "bottom_top", "min": 0.5, "max": 2, "start": -1, "end": 1}}}})");
     CHECK(c3.params().nonstationary == 1 && c3.params().multi_resolution_grid == 1 && c3.params().ls_max == 2.0);
+    // the rest of the wrapper and of the mean: "var", a bottom_top_left_right "ls", mean "color" / "emission" (GPF.cpp:1590-1606, GPF.hpp:808-818)
+    HipSparseConvNoiseMedium c5;
+    c5.fromJson(R"({"correlation_context": "renewal", "gaussian_process": {
+        "mean": {"type": "spherical", "radius": 1, "color": {"type": "noise", "noise": "left_right", "min": 0.2, "max": 0.9, "start": -1, "end": 1},
+                 "emission": {"type": "noise", "noise": "bottom_top", "min": 0, "max": 2}},
+        "covariance": {"type": "proc_nonstationary", "cov": {"type": "squared_exponential", "sigma": 0.1, "lengthScale": 0.05},
+        "ls": {"type": "noise", "noise": "bottom_top_left_right", "min": 0.5, "max": 2, "start": -1, "end": 1, "min2": 0.8, "max2": 1.5, "start2": -2, "end2": 2},
+        "var": {"type": "noise", "noise": "front_back", "min": 0.4, "max": 1.8, "start": -1, "end": 1}}}})");
+    CHECK(c5.params().ls_ramp_type == GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT && c5.params().ls_max2 == 1.5 && c5.params().ls_start2 == -2.0);
+    CHECK(c5.params().var.enabled == 1 && c5.params().var.type == GPIS_RAMP_FRONT_BACK && c5.params().var.max == 1.8);
+    CHECK(c5.params().mean_color.enabled == 1 && c5.params().mean_color.type == GPIS_RAMP_LEFT_RIGHT && c5.params().mean_color.min == 0.2);
+    CHECK(c5.params().mean_emission.enabled == 1 && c5.params().mean_emission.max == 2.0 && c5.params().mean_emission.end == 1.0);
+    CHECK(throws(R"({"correlation_context": "none", "gaussian_process": {"mean": {"color": {"noise": "rust"}}}})", "outside the built scope"));
     // calling the path before prepareForRender fails loudly
     ConstSampler s(0.5f);
     MediumState st;

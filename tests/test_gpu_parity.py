@@ -498,6 +498,54 @@ def test_multi_resolution_nonstationary(env, iso, oned):
     assert _close(got["t"][same], want["t"][same], 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("multires", [1, 0])
+def test_variance_field_btlr_color_emission(env, multires):
+    """The rest of the proc_nonstationary wrapper and of the mean: a "var" field (amplitude = var(p) * sigma,
+    GPF.cpp:1235-1237, 1638-1641), an "ls" field of type bottom_top_left_right (GPF.cpp:96-103, maxVal :124-138) and the
+    mean's "color" / "emission" (GPF.hpp:849-857, GPM.cpp:316-317).  Ramps go through device log/exp: toleranced."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C3")
+    params["impulse_density"] = 12
+    params["multi_resolution_grid"] = multires
+    params["isotropic_3d_sampling"] = multires          # world space without the grid, isotropic-ray space with it
+    params["correlation_context"] = pkg.CTX.RENEWAL
+    params["ls_ramp_type"] = 3
+    params["ls_min"], params["ls_max"], params["ls_start"], params["ls_end"] = 0.6, 1.4, -1.2, 1.2
+    params["ls_min2"], params["ls_max2"], params["ls_start2"], params["ls_end2"] = 0.8, 1.5, -1.0, 1.0
+    for key, typ, lo, hi in (("var", 0, 0.4, 1.8), ("mean_color", 1, 0.2, 0.9), ("mean_emission", 3, 0.1, 2.0)):
+        params[key]["enabled"], params[key]["type"] = 1, typ
+        params[key]["min"], params[key]["max"], params[key]["start"], params[key]["end"] = lo, hi, -1.0, 1.0
+        params[key]["min2"], params[key]["max2"], params[key]["start2"], params[key]["end2"] = 0.5, 1.5, -0.5, 0.5
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    d_g, d_o = med.derived(), orc.derived()
+    assert d_g["kernel_radius_world"] == d_o["kernel_radius_world"]
+    q = _queries(pkg, 1024, 71)
+    assert _close(med.eval_value(q)[0], orc.eval_value(q)[0], 1e-4, 1e-5)
+    assert _close(med.eval_gradient(q), orc.eval_gradient(q), 2e-4, 2e-4)
+    pts = np.random.default_rng(5).uniform(-1.4, 1.4, (4096, 3))
+    cg, eg = med.mean_color_emission(pts)
+    co, eo = orc.mean_color_emission(pts)
+    assert _close(cg, co, 1e-5, 1e-6) and _close(eg, eo, 1e-5, 1e-6)
+    assert co.min() > 0.19 and co.max() < 0.91 and eo.max() > 1.0 and (co[:, 0] == co[:, 2]).all()
+    scene = ob.default_scene_s(128, 72, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    for persistent in (1, 0):
+        med.set_option("persistent", persistent)
+        got, want = med.sample_distance(rays), orc.sample_distance(rays)
+        flips = int((got["exited"] != want["exited"]).sum())
+        assert flips <= max(1, len(rays) // 300), "hit/miss flips: %d of %d" % (flips, len(rays))
+        same = (got["exited"] == want["exited"]) & (got["ok"] == want["ok"])
+        assert _close(got["t"][same], want["t"][same], 1e-4, 1e-4)
+        assert _close(got["weight"][same], want["weight"][same], 1e-4, 1e-5)
+        hits = same & (want["exited"] == 0) & (want["ok"] == 1)
+        assert hits.sum() > 50 and (want["weight"][hits, 0] < 0.95).all()        # the colour reached the weight
+    # with the fields switched off the medium is the plain one again
+    plain = params.copy()
+    for key in ("var", "mean_color", "mean_emission"):
+        plain[key]["enabled"] = 0
+    assert not np.array_equal(pkg.Medium(plain).eval_value(q)[0], med.eval_value(q)[0])
+
+
 def test_nonstationary_brute_force(env):
     """proc_nonstationary without the multi-resolution grid (per-point kernel scale)."""
     pkg, ob, lib = env

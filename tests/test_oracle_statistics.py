@@ -112,3 +112,26 @@ def test_gradient_variance(pkg, ob):
         assert np.all(np.abs(var - 1.0) < 3 * TOL), (space, var)
         c = np.corrcoef(g.T)
         assert abs(c[0, 1]) < TOL and abs(c[0, 2]) < TOL and abs(c[1, 2]) < TOL
+
+
+def test_variance_field_scales_the_amplitude(pkg, ob):
+    """proc_nonstationary "var": the field's standard deviation at p is var(p) * sigma (GPF.cpp:1235-1237, 1638-1641), var
+    being the bottom_top ramp sqrt(exp(lerp(log((min+1)^2), log((max+1)^2), clamp((y - start) / (end - start))))) - 1
+    (GPF.cpp:43-55)."""
+    params = _params(pkg, "world", 16)
+    params["nonstationary"] = 1
+    params["multi_resolution_grid"] = 0
+    params["ls_ramp_type"] = 0
+    params["ls_min"], params["ls_max"], params["ls_start"], params["ls_end"] = 1.0, 1.0, -1.0, 1.0      # constant length scale
+    params["var"]["enabled"] = 1
+    params["var"]["type"] = 0
+    params["var"]["min"], params["var"]["max"], params["var"]["start"], params["var"]["end"] = 0.5, 2.0, -1.0, 1.0
+    orc = ob.Oracle(params, threads=8)
+    sigma = float(params["sigma"])
+    ys = [-1.5, -0.5, 0.0, 0.5, 1.5]
+    pts = [np.array([0.2, y, -0.1]) for y in ys]
+    vals = (_ensemble(pkg, orc, pts, (0.0, 0.0, 1.0)) - 0.25) / sigma
+    for y, v in zip(ys, vals):
+        u = min(max((y + 1.0) / 2.0, 0.0), 1.0)
+        var = np.sqrt(np.exp(np.log(1.5 ** 2) * (1 - u) + np.log(3.0 ** 2) * u)) - 1.0
+        assert abs(v.std() / var - 1.0) < TOL, (y, v.std(), var)
