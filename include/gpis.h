@@ -91,6 +91,17 @@ typedef struct gpis_ramp {
     double min2, max2, start2, end2; /* "min2", "max2", "start2", "end2"  (bottom_top_left_right) */
 } gpis_ramp;
 
+/* Stationary covariance kernels with a sparse-convolution splatting kernel (GPF.cpp).  Matérn with v = 1.5 needs Boost's
+ * cyl_bessel_k (GPF.cpp:1055, 1073), which is neither vendored nor installed: outside the built scope.  Matérn / Gabor kernels
+ * define no isotropic-space transform, no 1D kernel and no second derivative (GPF.hpp:2002-2110), so they are accepted for
+ * world-space 3D sampling with correlation context none / global / renewal. */
+typedef enum gpis_kernel_type {
+    GPIS_KERNEL_SQUARED_EXPONENTIAL = 0,   /* GPF.cpp:654-865 */
+    GPIS_KERNEL_MATERN = 1,                /* "matern": "sigma", "v" (0.5 or 2.5), "lengthScale", "aniso"     GPF.cpp:866-1082 */
+    GPIS_KERNEL_GABOR_ANISO = 2,           /* "gabor_aniso": "sigma", "a_inv", "f_inv", "omega"               GPF.cpp:1086-1150 */
+    GPIS_KERNEL_GABOR_ISO = 3              /* "gabor_iso": "sigma", "a_inv", "f_inv"                          GPF.cpp:1155-1214 */
+} gpis_kernel_type;
+
 typedef struct gpis_mean {
     int32_t type;          /* gpis_mean_type */
     float radius;          /* spherical */
@@ -154,6 +165,12 @@ typedef struct gpis_params {
     gpis_ramp var;                   /* "var": getVariance(p) (GPF.cpp:1638-1641); the noise amplitude becomes var(p) * sigma (GPF.cpp:1235-1237) */
     gpis_ramp mean_color;            /* mean "color":    MediumSample.weight *= color(p) on a hit (GPM.cpp:316) */
     gpis_ramp mean_emission;         /* mean "emission": MediumSample.emission (GPM.cpp:317) — gpis_mean_color_emission_* */
+    /* --- other stationary kernels (sigma / length_scale / aniso above are shared) --- */
+    int32_t kernel_type;             /* gpis_kernel_type */
+    float matern_v;                  /* "v" */
+    float gabor_a_inv, gabor_f_inv;  /* "a_inv", "f_inv" (the reference stores a = 1/a_inv, f = 1/f_inv) */
+    float gabor_omega[3];            /* "omega" (normalised at construction, GPF.cpp:1095) */
+    int32_t _pad2;
 } gpis_params;
 
 /*

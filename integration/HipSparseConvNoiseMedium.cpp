@@ -140,6 +140,24 @@ void HipSparseConvNoiseMedium::readGaussianProcess(JsonPtr gp)
         c.getField("type", type);
         if (type == "squared_exponential") {
             readSquaredExponential(c);
+        } else if (type == "matern") {                     // MaternCovariance::fromJson, GPFunctions.cpp:866-876
+            _params.kernel_type = GPIS_KERNEL_MATERN;
+            c.getField("sigma", _params.sigma);
+            c.getField("v", _params.matern_v);
+            c.getField("lengthScale", _params.length_scale);
+            Vec3f aniso(_params.aniso[0], _params.aniso[1], _params.aniso[2]);
+            c.getField("aniso", aniso);
+            for (int i = 0; i < 3; ++i) _params.aniso[i] = aniso[i];
+            c.getField("localScale", _params.local_scale);
+        } else if (type == "gabor_aniso" || type == "gabor_iso") {     // GPFunctions.cpp:1086-1096, 1155-1162
+            _params.kernel_type = type == "gabor_aniso" ? GPIS_KERNEL_GABOR_ANISO : GPIS_KERNEL_GABOR_ISO;
+            c.getField("sigma", _params.sigma);
+            c.getField("a_inv", _params.gabor_a_inv);
+            c.getField("f_inv", _params.gabor_f_inv);
+            Vec3f omega(_params.gabor_omega[0], _params.gabor_omega[1], _params.gabor_omega[2]);
+            c.getField("omega", omega);
+            for (int i = 0; i < 3; ++i) _params.gabor_omega[i] = omega[i];
+            c.getField("localScale", _params.local_scale);
         } else if (type == "proc_nonstationary") {      // GPFunctions.cpp:1590-1606, GPFunctions.hpp:2211-2217
             _params.nonstationary = 1;
             bool grid = _params.multi_resolution_grid != 0;

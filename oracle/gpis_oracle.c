@@ -280,6 +280,7 @@ struct oracle_medium {
     float base;           /* SCN.cpp:32 */
     /* ProceduralNoiseVec::fromJson, GPF.hpp:765-776 */
     double ls_scale, ls_offset;
+    float gabor_a, gabor_f, gabor_omega[3];   /* _a = 1/a_inv, _f = 1/f_inv, normalised omega (GPF.cpp:1088-1096) */
     float ls_maxval;      /* maxVal(), GPF.cpp:124-138 */
     /* GaussianProcessMedium::prepareForRender, GPM.cpp:152-158 */
     float sigma_a[3], sigma_s[3], sigma_t[3];
@@ -426,9 +427,85 @@ static float cov_amplitude(const oracle_medium *m, v3f p)
     double var = m->P.var.enabled ? ramp_of(&m->P.var, v3d_of(p)) : 1.0;
     return (float)(var * m->P.sigma);
 }
+/* ---- Matérn (v = 0.5, 2.5) and Gabor kernels: GPF.cpp:866-1214 ---------------------------------------------
+ * The reference evaluates these in double (exp / pow / cos / sin of libm) and narrows to float. */
+static float other_kernel_radius(const oracle_medium *m, int isIdentity, float localScale)
+{
+    float scale_factor = m->kernel_scale;
+    if (m->P.kernel_type == GPIS_KERNEL_MATERN) {                        /* GPF.cpp:1020-1025 */
+        if (isIdentity)
+            return scale_factor;
+        float la[3];
+        for (int i = 0; i < 3; ++i) {                                    /* fromJson, GPF.cpp:873-875 + filterWithZero */
+            la[i] = m->P.length_scale / sqrtf(m->P.aniso[i]);
+            if (isinf(la[i]) || isnan(la[i])) la[i] = 0;
+        }
+        float mx = la[0] > la[1] ? la[0] : la[1];
+        mx = mx > la[2] ? mx : la[2];
+        return (float)(scale_factor * localScale * sqrt(2) / 2 * mx);
+    }
+    if (m->P.kernel_type == GPIS_KERNEL_GABOR_ANISO)                     /* GPF.cpp:1127-1130 */
+        return (float)(scale_factor * sqrt(2) / 2 * 1.0 / m->gabor_a);
+    return (float)(scale_factor * sqrt(2) / 4 * 1.0 / m->gabor_a);       /* GPF.cpp:1192-1195 */
+}
+static float other_variance3d(const oracle_medium *m, float impulseDensity, float kernelRadius)
+{
+    double impulseDensityUnitArea = impulseDensity / (kernelRadius * kernelRadius * kernelRadius);
+    double integralKernelSquared;
+    const float l = m->P.length_scale, a = m->gabor_a, f = m->gabor_f;
+    if (m->P.kernel_type == GPIS_KERNEL_MATERN) {                        /* GPF.cpp:1029-1046 */
+        if (m->P.matern_v == 0.5) integralKernelSquared = 2.0 * M_PI * l;
+        else integralKernelSquared = M_PI * pow(l, 3) / (5 * sqrt(5));
+    } else if (m->P.kernel_type == GPIS_KERNEL_GABOR_ANISO) {            /* GPF.cpp:1134-1138 */
+        float q = f / a;
+        integralKernelSquared = pow(1.0 / a, 3) * (1 + exp(-2.0 * M_PI * (q * q))) / (4 * sqrt(2));
+    } else {                                                             /* GPF.cpp:1199-1203 */
+        integralKernelSquared = 2 * sqrt(2) * M_PI * (f * f) / a * (1 - exp(-2 * M_PI * f / (a * a)));
+    }
+    return (float)(impulseDensityUnitArea * integralKernelSquared);
+}
+static v4f other_splat3d(const oracle_medium *m, v3f ab)
+{
+    const float l = m->P.length_scale, a = m->gabor_a, f = m->gabor_f;
+    if (m->P.kernel_type == GPIS_KERNEL_MATERN) {                        /* GPF.cpp:1048-1082 */
+        double abLen = sqrtf(v3_length_sq(ab));                          /* Vec3f::length() */
+        float val;
+        float gs;
+        if (m->P.matern_v == 0.5) {
+            val = (float)(exp(-abLen / l) / abLen);
+            gs = -(float)(exp(-abLen / l) * (1 / pow(abLen, 3) - 1 / (pow(abLen, 2) * l)));
+        } else {
+            val = (float)exp(-sqrt(5.) * abLen / l);
+            gs = -(float)(exp(-sqrt(5.) * abLen / l) * sqrt(5.) / l / abLen);
+        }
+        return v4(val, gs * ab.x, gs * ab.y, gs * ab.z);
+    }
+    if (m->P.kernel_type == GPIS_KERNEL_GABOR_ANISO) {                   /* GPF.cpp:1140-1150 */
+        v3f om = v3(m->gabor_omega[0], m->gabor_omega[1], m->gabor_omega[2]);
+        float od = v3_dot(om, ab);
+        float val = (float)(exp(-M_PI * (a * a) * v3_length_sq(ab)) * cos(2.f * M_PI * f * od));
+        float A = (float)exp(-M_PI * (a * a) * v3_length_sq(ab));
+        float B = (float)cos(2.f * M_PI * f * od);
+        float c1 = -(float)(A * sin(2.f * M_PI * f * od) * 2.f * M_PI * f);
+        float c2 = (float)(B * A * 2.f * M_PI * (a * a));
+        v3f g = v3_sub(v3_scale(om, c1), v3_scale(ab, c2));
+        return v4(val, g.x, g.y, g.z);
+    }
+    {                                                                    /* GPF.cpp:1205-1214 */
+        float r = sqrtf(v3_length_sq(ab));
+        float ar = a * r;
+        float val = (float)(exp(-M_PI * (ar * ar)) * 2 * f / r * sin(2 * M_PI * f * r));
+        float gs = (float)(2 * f * exp(-M_PI * (a * a) * v3_length_sq(ab)) *
+                           (-sin(2 * M_PI * f * r) / pow(r, 3) - 2 * M_PI * (a * a) * sin(2 * M_PI * f * r) / r + 2 * M_PI * f * cos(2 * M_PI * f * r) / (r * r)));
+        return v4(val, gs * ab.x, gs * ab.y, gs * ab.z);
+    }
+}
+
 /* SquaredExponentialCovariance::splattingKernelRadius, GPF.cpp:696-709 */
 static float se_kernel_radius(const oracle_medium *m, int isIdentity, float localScale)
 {
+    if (m->P.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
+        return other_kernel_radius(m, isIdentity, localScale);
     float scale_factor = m->kernel_scale;
     if (isIdentity)
         return scale_factor;
@@ -459,6 +536,8 @@ static float cov_kernel_radius(const oracle_medium *m, int isIdentity, float loc
 static float se_variance3d(const oracle_medium *m, float impulseDensity, float kernelRadius, int isIdentity,
                            float globalScale, float localScale)
 {
+    if (m->P.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
+        return other_variance3d(m, impulseDensity, kernelRadius);
     double impulseDensityUnitArea = impulseDensity / (kernelRadius * kernelRadius * kernelRadius);
     double covDeterminantSqrt = 1.0;
     if (!isIdentity) {
@@ -568,6 +647,8 @@ static void se_splat3d_hess(v3f ab, const float *A, float *H)
 /* CovarianceFunction::splattingKernel3D, GPF.cpp:552-562 */
 static v4f cov_splat3d(const oracle_medium *m, v3f pa, v3f pb, int isCov, int isIso, float globalScale, v3f p_world)
 {
+    if (m->P.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
+        return other_splat3d(m, v3_sub(pa, pb));      /* StationaryCovariance forwards a - b, GPF.hpp:1607-1612 */
     float localScale = cov_ns_scale(m, p_world);
     float A[9];
     se_inv_cov_mtx(m, isCov, isIso, globalScale, localScale, A);
@@ -579,6 +660,12 @@ static v4f cov_splat3d(const oracle_medium *m, v3f pa, v3f pb, int isCov, int is
 /* CovarianceFunction::splattingKernel3DGrad, GPF.cpp:564-577 */
 static v4f cov_splat3d_grad(const oracle_medium *m, v3f pa, v3f pb, v3f coeff, int isCov, int isIso, float globalScale, v3f p_world)
 {
+    if (m->P.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
+        /* these kernels do not override splattingKernel3D2ndGrad: the base returns a zero matrix (GPF.hpp:1518-1521) */
+        v4f k = other_splat3d(m, v3_sub(pa, pb));
+        v4f vx = v4(k.gx, 0.f, 0.f, 0.f), vy = v4(k.gy, 0.f, 0.f, 0.f), vz = v4(k.gz, 0.f, 0.f, 0.f);
+        return v4_add(v4_add(v4_scale(vx, coeff.x), v4_scale(vy, coeff.y)), v4_scale(vz, coeff.z));
+    }
     float localScale = cov_ns_scale(m, p_world);
     float A[9], H[9];
     se_inv_cov_mtx(m, isCov, isIso, globalScale, localScale, A);
@@ -1543,6 +1630,7 @@ void oracle_default_params(gpis_params *p)
     p->local_scale = 3.0f;                                                           /* GPF.hpp:1729 */
     p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;              /* GPF.hpp:694-695 */
     p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          /* GPF.hpp:697-698 */
+    p->matern_v = 0.5f; p->gabor_a_inv = 1.f; p->gabor_f_inv = 1.f; p->gabor_omega[0] = 1.f;   /* GPF.hpp:1964, 2041, 2079 */
     {
         gpis_ramp *ramps[3] = {&p->var, &p->mean_color, &p->mean_emission};
         for (int i = 0; i < 3; ++i) {
@@ -1569,6 +1657,13 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
         (params->mean_emission.enabled && (params->mean_emission.type < 0 || params->mean_emission.type > 3)))
         return fail("invalid procedural noise type");
     if (params->var.enabled && !params->nonstationary) return fail("a var field needs the proc_nonstationary wrapper");
+    if (params->kernel_type < 0 || params->kernel_type > 3) return fail("invalid kernel type");
+    if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
+        if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 2.5f)
+            return fail("Matern kernel: v must be 0.5 or 2.5 (1.5 needs Boost's cyl_bessel_k)");
+        if (params->isotropic_3d_sampling || params->sampling_1d || params->nonstationary || params->correlation_context == GPIS_CTX_RENEWAL_PLUS)
+            return fail("Matern / Gabor kernels: world-space 3D sampling with context none / global / renewal only");
+    }
     oracle_medium *m = (oracle_medium *)calloc(1, sizeof *m);
     if (!m) return GPIS_ERR_DEVICE;
     m->P = *params;
@@ -1607,6 +1702,13 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
     m->multi_res = P->nonstationary && P->multi_resolution_grid;
     m->base = 2.5f;
     /* ramp, GPF.hpp:773-774 and maxVal GPF.cpp:124-130 */
+    m->gabor_a = (float)(1.0 / P->gabor_a_inv);
+    m->gabor_f = (float)(1.0 / P->gabor_f_inv);
+    {   /* Vec3f::normalize(): *this *= 1/length */
+        float l2 = 0.f; l2 += P->gabor_omega[0] * P->gabor_omega[0]; l2 += P->gabor_omega[1] * P->gabor_omega[1]; l2 += P->gabor_omega[2] * P->gabor_omega[2];
+        float inv = 1.0f / sqrtf(l2);
+        for (int i = 0; i < 3; ++i) m->gabor_omega[i] = P->gabor_omega[i] * inv;
+    }
     m->ls_scale = 1.0 / (P->ls_end - P->ls_start);
     m->ls_offset = -P->ls_start * m->ls_scale;
     {   /* ProceduralNoiseVec::maxVal, GPF.cpp:124-138 */

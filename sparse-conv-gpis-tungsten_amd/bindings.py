@@ -48,6 +48,7 @@ PARAMS = np.dtype([
     ("mean", MEAN), ("has_mean_additional", "<i4"), ("_pad1", "<i4"), ("mean_additional", MEAN),
     ("ls_min2", "<f8"), ("ls_max2", "<f8"), ("ls_start2", "<f8"), ("ls_end2", "<f8"),
     ("var", RAMP), ("mean_color", RAMP), ("mean_emission", RAMP),
+    ("kernel_type", "<i4"), ("matern_v", "<f4"), ("gabor_a_inv", "<f4"), ("gabor_f_inv", "<f4"), ("gabor_omega", "<f4", 3), ("_pad2", "<i4"),
 ], align=True)
 
 RAY_IN = np.dtype([
@@ -135,6 +136,7 @@ def default_params():
     """Reference defaults (SCNM.cpp:17-34, GPM.cpp:86-95, GPF.hpp:1729,1784) as a PARAMS record."""
     p = np.zeros((), dtype=PARAMS)
     p["abi_version"] = 2
+    p["matern_v"], p["gabor_a_inv"], p["gabor_f_inv"], p["gabor_omega"] = 0.5, 1.0, 1.0, (1.0, 0.0, 0.0)
     p["step_size"] = 0.01
     p["min_step"] = 8
     p["impulse_density"] = 3.0

@@ -72,6 +72,11 @@ struct DevModel {
     DevRamp ls;                   // the same "ls" field in the general form (bottom_top_left_right needs the second ramp)
     DevRamp var, color, emission; // "var" (GPF.cpp:1638-1641), mean "color" / "emission" (GPF.hpp:849-857)
     float sigma_raw;              // the stationary kernel's sigma (sparseConvNoiseAmplitude() of GPF.cpp:711)
+    // Matérn / Gabor kernels (GPF.cpp:866-1214): world-space 3D sampling only; radius_world / norm3d_world hold their constants
+    int32_t kernel_type;          // gpis_kernel_type
+    float matern_v, k_l;          // "v", "lengthScale"
+    float gabor_a, gabor_f;       // 1 / a_inv, 1 / f_inv
+    float gabor_omega[3];         // normalised
     // multi-resolution level tables (host libm: powf / logf), index level - kLevelMin
     float level_scale[kLevels];           // powf(2.5, level)
     int32_t level_addseed[kLevels];       // (int)floorf(logf(level_scale)/logf(2.5))
@@ -525,6 +530,7 @@ GPIS_DEV double lerp_d(double a, double b, double ratio) { return a * (1.0 - rat
 // generic: every flag read at run time.  Its names are visible in gpis through a using-directive
 // (not an inline namespace: ADL must not see them from inside the specialised namespaces).
 #define GPIS_PATH_NS generic
+#define GPIS_FLAG_other_kernels(M) ((M).kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
 #define GPIS_FLAG_sampling_1d(M) ((M).sampling_1d)
 #define GPIS_FLAG_multi_res(M) ((M).multi_res)
 #define GPIS_FLAG_nonstationary(M) ((M).nonstationary)
@@ -535,6 +541,7 @@ namespace gpis { using namespace generic; }
 
 // 1D sampling along the ray (config C2)
 #define GPIS_PATH_NS spec_1d
+#define GPIS_FLAG_other_kernels(M) 0
 #define GPIS_FLAG_sampling_1d(M) 1
 #define GPIS_FLAG_multi_res(M) ((M).multi_res)
 #define GPIS_FLAG_nonstationary(M) ((M).nonstationary)
@@ -544,6 +551,7 @@ namespace gpis { using namespace generic; }
 
 // 3D sampling, stationary kernel (config C0 and its per-path variants, C1 without the fast path)
 #define GPIS_PATH_NS spec_3d
+#define GPIS_FLAG_other_kernels(M) 0
 #define GPIS_FLAG_sampling_1d(M) 0
 #define GPIS_FLAG_multi_res(M) 0
 #define GPIS_FLAG_nonstationary(M) 0
@@ -553,6 +561,7 @@ namespace gpis { using namespace generic; }
 
 // 3D sampling, non-stationary length scale on the multi-resolution grid (config C3)
 #define GPIS_PATH_NS spec_3d_multires
+#define GPIS_FLAG_other_kernels(M) 0
 #define GPIS_FLAG_sampling_1d(M) 0
 #define GPIS_FLAG_multi_res(M) 1
 #define GPIS_FLAG_nonstationary(M) 1

@@ -44,7 +44,7 @@ struct FastTable {
 
 inline bool fast_supported(const DevModel &M)
 {
-    return M.single_realization && !M.sampling_1d && !M.nonstationary && !M.use_aniso_mtx && !M.absorption_only && !M.color.enabled &&
+    return M.single_realization && !M.sampling_1d && !M.nonstationary && !M.use_aniso_mtx && !M.absorption_only && !M.color.enabled && M.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL &&
            M.n_impulses >= 1 && M.n_impulses <= 64;
 }
 __global__ void __launch_bounds__(64) k_fast_build_table(uint32_t seed, int half, int stride, float4 *__restrict__ cells)

@@ -298,6 +298,43 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
         M.exp_arg_max = (v == v && v >= 0.f) ? v : 3.4e38f;
     }
     M.norm3d_iso = sqrtf(variance3d(P.impulse_density, M.radius_iso, true, 1.0f, 1.0f));
+    // Matérn / Gabor kernels: their own radius and variance (GPF.cpp:1020-1046, 1127-1138, 1192-1203); host libm as the reference
+    M.kernel_type = P.kernel_type;
+    M.matern_v = P.matern_v;
+    M.k_l = P.length_scale;
+    M.gabor_a = (float)(1.0 / P.gabor_a_inv);
+    M.gabor_f = (float)(1.0 / P.gabor_f_inv);
+    {
+        float l2 = 0.f; l2 += P.gabor_omega[0] * P.gabor_omega[0]; l2 += P.gabor_omega[1] * P.gabor_omega[1]; l2 += P.gabor_omega[2] * P.gabor_omega[2];
+        const float inv = 1.0f / sqrtf(l2);
+        for (int i = 0; i < 3; ++i) M.gabor_omega[i] = P.gabor_omega[i] * inv;
+    }
+    if (P.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
+        const float l = P.length_scale, a = M.gabor_a, f = M.gabor_f;
+        double iks;
+        if (P.kernel_type == GPIS_KERNEL_MATERN) {
+            float la[3];
+            for (int i = 0; i < 3; ++i) {
+                la[i] = l / sqrtf(P.aniso[i]);
+                if (std::isinf(la[i]) || std::isnan(la[i])) la[i] = 0;
+            }
+            float mx = la[0] > la[1] ? la[0] : la[1];
+            mx = mx > la[2] ? mx : la[2];
+            M.radius_world = (float)(M.kernel_scale * 1.0f * sqrt(2) / 2 * mx);
+            iks = P.matern_v == 0.5 ? 2.0 * M_PI * l : M_PI * pow(l, 3) / (5 * sqrt(5));
+        } else if (P.kernel_type == GPIS_KERNEL_GABOR_ANISO) {
+            M.radius_world = (float)(M.kernel_scale * sqrt(2) / 2 * 1.0 / a);
+            const float q = f / a;
+            iks = pow(1.0 / a, 3) * (1 + exp(-2.0 * M_PI * (q * q))) / (4 * sqrt(2));
+        } else {
+            M.radius_world = (float)(M.kernel_scale * sqrt(2) / 4 * 1.0 / a);
+            iks = 2 * sqrt(2) * M_PI * (f * f) / a * (1 - exp(-2 * M_PI * f / (a * a)));
+        }
+        const float R = M.radius_world;
+        const double idua = P.impulse_density / (R * R * R);
+        M.norm3d_world = sqrtf((float)(idua * iks));
+        M.radius_iso = M.kernel_scale;      // splattingKernelRadius(true, .) of these kernels; unused (world space only)
+    }
     {
         double idua = P.impulse_density / M.radius_iso;
         M.norm1d = sqrtf((float)(idua * (M.sqrt_pi * 1.0f)));
@@ -1089,6 +1126,7 @@ extern "C" void gpis_default_params(gpis_params *p)
     p->local_scale = 3.0f;
     p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;
     p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          // GPF.hpp:694-699
+    p->matern_v = 0.5f; p->gabor_a_inv = 1.f; p->gabor_f_inv = 1.f; p->gabor_omega[0] = 1.f;   // GPF.hpp:1964, 2041, 2079
     gpis_ramp *ramps[3] = {&p->var, &p->mean_color, &p->mean_emission};
     for (gpis_ramp *r : ramps) { r->min = 1.; r->max = 500.; r->start = 0.; r->end = 1.; r->min2 = 1.; r->max2 = 500.; r->start2 = 0.; r->end2 = 1.; }
     p->mean.type = GPIS_MEAN_SPHERICAL; p->mean.radius = 1.f;
@@ -1112,6 +1150,14 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         for (const gpis_ramp *r : ramps)
             if (r->enabled && (r->type < 0 || r->type > 3)) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type (sandstone / rust are outside the built scope)");
         if (params->var.enabled && !params->nonstationary) return set_err(GPIS_ERR_INVALID_ARG, "a \"var\" field needs the proc_nonstationary wrapper");
+    }
+    if (params->kernel_type < 0 || params->kernel_type > 3) return set_err(GPIS_ERR_INVALID_ARG, "invalid kernel type");
+    if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
+        if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 2.5f)
+            return set_err(GPIS_ERR_UNSUPPORTED, "Matern kernel: v must be 0.5 or 2.5 (1.5 needs Boost's cyl_bessel_k, GPF.cpp:1055)");
+        if (params->isotropic_3d_sampling || params->sampling_1d || params->nonstationary || params->correlation_context == GPIS_CTX_RENEWAL_PLUS)
+            return set_err(GPIS_ERR_UNSUPPORTED, "Matern / Gabor kernels: world-space 3D sampling with correlation context none / global / renewal only "
+                                                 "(they define no isotropic transform, 1D kernel or second derivative, GPF.hpp:2002-2110)");
     }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -1414,6 +1460,8 @@ static int launch_persist(gpis_medium *m, PersistArgs a, hipStream_t s)
     const int w = WANT_SAMPLE ? 0 : 4;
     if (H.sampling_1d)
         return launch_persist_t<spec_1d::Persist, WANT_SAMPLE>(m, w + 0, a, s);
+    if (H.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
+        return launch_persist_t<generic::Persist, WANT_SAMPLE>(m, w + 3, a, s);
     if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid)
         return launch_persist_t<spec_3d::Persist, WANT_SAMPLE>(m, w + 1, a, s);
     if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
@@ -1465,7 +1513,7 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
     const unsigned grid = grid_of(n, kBlock);
     if (H.sampling_1d)
         k_sample_distance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
-    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid)
+    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL)
         k_sample_distance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
     else if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
         k_sample_distance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
@@ -1510,7 +1558,7 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
     const unsigned grid = grid_of(n, kBlock);
     if (H.sampling_1d)
         k_transmittance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
-    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid)
+    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL)
         k_transmittance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
     else if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
         k_transmittance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);

@@ -241,6 +241,20 @@ void HipSparseConvNoiseMedium::fromJson(const std::string &json)
             if (const JValue *t = c->get("type")) type = t->str;
             if (type == "squared_exponential") {
                 readSE(*c, p);
+            } else if (type == "matern") {                         // MaternCovariance::fromJson, GPF.cpp:866-876
+                p.kernel_type = GPIS_KERNEL_MATERN;
+                getNum(*c, "sigma", p.sigma);
+                getNum(*c, "v", p.matern_v);
+                getNum(*c, "lengthScale", p.length_scale);
+                getVec3(*c, "aniso", p.aniso);
+                getNum(*c, "localScale", p.local_scale);
+            } else if (type == "gabor_aniso" || type == "gabor_iso") {   // GPF.cpp:1086-1096, 1155-1162
+                p.kernel_type = type == "gabor_aniso" ? GPIS_KERNEL_GABOR_ANISO : GPIS_KERNEL_GABOR_ISO;
+                getNum(*c, "sigma", p.sigma);
+                getNum(*c, "a_inv", p.gabor_a_inv);
+                getNum(*c, "f_inv", p.gabor_f_inv);
+                getVec3(*c, "omega", p.gabor_omega);
+                getNum(*c, "localScale", p.local_scale);
             } else if (type == "proc_nonstationary") {           // GPF.hpp:2211-2217, GPF.cpp:1590-1606
                 p.nonstationary = 1;
                 getNum(*c, "multiResolutionGrid", p.multi_resolution_grid);

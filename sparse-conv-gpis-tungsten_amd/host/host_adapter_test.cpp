@@ -58,7 +58,12 @@ static void test_parse()
     CHECK(throws(R"({"correlation_context": "sometimes"})", "Invalid correlation context"));
     CHECK(throws(R"({"step_size": 0.01})", "Invalid correlation context: 'goldfish'"));
     CHECK(throws(R"({"correlation_context": "none", "1D_sampling_scheme": "both"})", "Invalid sparse conv sampling scheme"));
-    CHECK(throws(R"({"correlation_context": "none", "gaussian_process": {"covariance": {"type": "matern"}}})", "Unsupported covariance"));
+    CHECK(throws(R"({"correlation_context": "none", "gaussian_process": {"covariance": {"type": "thin_plate"}}})", "Unsupported covariance"));
+    HipSparseConvNoiseMedium c6;
+    c6.fromJson(R"({"correlation_context": "none", "gaussian_process": {"covariance": {"type": "matern", "sigma": 0.2, "v": 2.5, "lengthScale": 0.07, "aniso": [1, 2, 1]}}})");
+    CHECK(c6.params().kernel_type == GPIS_KERNEL_MATERN && c6.params().matern_v == 2.5f && c6.params().length_scale == 0.07f && c6.params().aniso[1] == 2.f);
+    c6.fromJson(R"({"correlation_context": "none", "gaussian_process": {"covariance": {"type": "gabor_aniso", "sigma": 0.1, "a_inv": 0.08, "f_inv": 0.06, "omega": [0, 1, 0]}}})");
+    CHECK(c6.params().kernel_type == GPIS_KERNEL_GABOR_ANISO && c6.params().gabor_a_inv == 0.08f && c6.params().gabor_omega[1] == 1.f);
     CHECK(HipSparseConvNoiseMedium::stringToCorrelationContext("renewal+") == GPCorrelationContext::RenewalPlus);
     CHECK(HipSparseConvNoiseMedium::stringToSamplingScheme1D("MIS") == SparseConv1DSamplingScheme::MIS);
     HipSparseConvNoiseMedium c3;

@@ -546,6 +546,57 @@ def test_variance_field_btlr_color_emission(env, multires):
     assert not np.array_equal(pkg.Medium(plain).eval_value(q)[0], med.eval_value(q)[0])
 
 
+@pytest.mark.parametrize("kernel", ["matern_0.5", "matern_2.5", "gabor_aniso", "gabor_iso"])
+def test_matern_and_gabor_kernels(env, kernel):
+    """Matérn (v = 1/2, 5/2: closed forms; 3/2 needs Boost's Bessel K) and Gabor kernels (GPF.cpp:1020-1082,
+    1127-1214) in world-space 3D sampling.  The reference evaluates them in double through libm; the device uses its own
+    exp / pow / sin / cos: toleranced."""
+    pkg, ob, lib = env
+    p = pkg.params_for_config("C0")
+    p["single_realization"] = 0
+    p["correlation_context"] = pkg.CTX.RENEWAL
+    p["impulse_density"] = 12
+    if kernel.startswith("matern"):
+        p["kernel_type"], p["matern_v"] = 1, float(kernel.split("_")[1])
+        p["aniso"] = (1.0, 0.7, 1.3)
+    else:
+        p["kernel_type"] = 2 if kernel == "gabor_aniso" else 3
+        p["gabor_a_inv"], p["gabor_f_inv"], p["gabor_omega"] = 0.08, 0.06, (0.3, 1.0, -0.2)
+    med, orc = pkg.Medium(p), ob.Oracle(p, threads=16)
+    d_g, d_o = med.derived(), orc.derived()
+    assert d_g["kernel_radius_world"] == d_o["kernel_radius_world"] and d_g["norm3d_world"] == d_o["norm3d_world"]
+    q = _queries(pkg, 2048, 81)
+    assert _close(med.eval_value(q)[0], orc.eval_value(q)[0], 2e-4, 2e-5)
+    assert _close(med.eval_gradient(q), orc.eval_gradient(q), 5e-4, 5e-3)
+    scene = ob.default_scene_s(128, 72, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    want = orc.sample_distance(rays, want_coeff=True)
+    sh = shadow_rays_from(ob, scene, rays, us, want[0])
+    batch = np.concatenate([rays, sh])
+    want = orc.sample_distance(batch, want_coeff=True)
+    for persistent in (1, 0):
+        med.set_option("persistent", persistent)
+        got = med.sample_distance(batch, want_coeff=True)
+        flips = int((got[0]["exited"] != want[0]["exited"]).sum())
+        assert flips <= max(1, len(batch) // 300), (kernel, persistent, flips, len(batch))
+        same = got[0]["exited"] == want[0]["exited"]
+        assert _close(got[0]["t"][same], want[0]["t"][same], 1e-4, 1e-4)
+        assert _close(got[1]["value_scale"][same], want[1]["value_scale"][same], 1e-3, 1e-4)
+        assert (med.transmittance(batch) != orc.transmittance(batch)).sum() <= max(1, len(batch) // 300)
+    # outside their scope the media are refused, loudly, by both implementations
+    bad = p.copy()
+    bad["isotropic_3d_sampling"] = 1
+    with pytest.raises(RuntimeError):
+        pkg.Medium(bad)
+    with pytest.raises(Exception):
+        ob.Oracle(bad)
+    if kernel.startswith("matern"):
+        bad = p.copy()
+        bad["matern_v"] = 1.5
+        with pytest.raises(RuntimeError):
+            pkg.Medium(bad)
+
+
 def test_nonstationary_brute_force(env):
     """proc_nonstationary without the multi-resolution grid (per-point kernel scale)."""
     pkg, ob, lib = env
