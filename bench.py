@@ -329,7 +329,7 @@ def main():
             roof = {"bound": "valu_issue", "kernel": kernel, "achieved": None, "peak": N_SIMD * PEAK_CLOCK_HZ / 1e12, "unit": "T SIMD issue cycles/s",
                     "frac": None, "traffic": None, "note": "profiles/r02_issue_model.json not found"}
         if True:
-            roof["kernel_ms"] = {names[0]: prof[0][0], names[1]: prof[1][0]}
+            roof["kernel_ms"] = {names[0]: prof[0][0] / max(prof[0][1], 1), names[1]: prof[1][0] / max(prof[1][1], 1)}     # per launch
             roof["launches"] = launches
             roof["evals_per_s"] = n_eval_all / dt_max
             roof["certified_steps_per_s"] = n_guide / dt_max

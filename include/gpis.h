@@ -171,6 +171,11 @@ typedef struct gpis_params {
     float gabor_a_inv, gabor_f_inv;  /* "a_inv", "f_inv" (the reference stores a = 1/a_inv, f = 1/f_inv) */
     float gabor_omega[3];            /* "omega" (normalised at construction, GPF.cpp:1095) */
     int32_t _pad2;
+    /* --- "aniso" field of proc_nonstationary (GPF.cpp:1600-1602): an angle in units of pi/2 that turns the in-plane anisotropy
+     *     (axis ratio 1.5 : 1/1.5 : 1, hard-coded in the reference, GPF.hpp:2372) of the splatting kernel about z
+     *     (getNonstationaryAniso3D, GPF.cpp:1678-1689).  Built for 3D sampling (world and isotropic-ray space); with 1D sampling
+     *     the medium is refused (getNonstationaryAniso1D / ...CovSplatCov1D, GPF.cpp:1691-1727, are outside the built scope). --- */
+    gpis_ramp aniso_field;
 } gpis_params;
 
 /*

@@ -180,6 +180,8 @@ void HipSparseConvNoiseMedium::readGaussianProcess(JsonPtr gp)
             }
             if (auto var = c["var"])                     // GPFunctions.cpp:1593-1595
                 readRamp(var, _params.var);
+            if (auto an = c["aniso"])                    // GPFunctions.cpp:1600-1602
+                readRamp(an, _params.aniso_field);
         } else {
             FAIL("hip_sparse_conv_noise: unsupported covariance type: '%s'", type);
         }

@@ -528,7 +528,7 @@ static float cov_kernel_radius(const oracle_medium *m, int isIdentity, float loc
 {
     if (m->P.nonstationary) {
         localScale = (float)(localScale * (m->P.multi_resolution_grid ? 1.0 : (double)cov_max_lateral_scale(m)));
-        localScale *= 1.f; /* sparseConvNoiseMaxAnisotropyScale() without an aniso field */
+        localScale *= m->P.aniso_field.enabled ? 1.5f : 1.f; /* sparseConvNoiseMaxAnisotropyScale(), GPF.cpp:1743-1747 */
     }
     return se_kernel_radius(m, isIdentity, localScale);
 }
@@ -602,11 +602,50 @@ static float cov_splat_cov_1d(const oracle_medium *m, v3f pq, v3f pc)
     return sqrtf(scale);
 }
 
-/* SE::getInvCovMtx, GPF.cpp:774-802 (aniso_inv is always null without an aniso field) */
-static void se_inv_cov_mtx(const oracle_medium *m, int isCov, int isIsotropic, float globalScale, float localScale, float *out)
+/* ProceduralNonstationaryCovariance::getNonstationaryAniso3D, GPF.cpp:1678-1689: the "aniso" field gives an angle in units
+ * of pi/2; the matrix is compute_ansio_full(angle, (1.5, 1/1.5, 1)) = (S V)^T (S V) with V the rotation block, GPF.cpp:27-40
+ * (_anisotropyOnAxis = 1.5, GPF.hpp:2372).  Returns 0 without a field (the reference's null pointer). */
+static int cov_ns_aniso3d(const oracle_medium *m, v3f p_world, float *out)
+{
+    if (!m->P.aniso_field.enabled)
+        return 0;
+    const float PI_HALF = PI_F * 0.5f;                               /* Angle.hpp:9 */
+    float angle = (float)(ramp_of(&m->P.aniso_field, v3d_of(p_world)) * PI_HALF);
+    float V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, S[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, SV[9], SVt[9];
+    M(V, 0, 0) = cosf(angle);
+    M(V, 0, 1) = sinf(angle);
+    M(V, 1, 0) = -sinf(angle);
+    M(V, 1, 1) = cosf(angle);
+    M(S, 0, 0) = 1.5f; M(S, 1, 1) = 1.f / 1.5f; M(S, 2, 2) = 1.f;
+    mat3_matmul_eig(S, V, SV);
+    mat3_transpose(SV, SVt);
+    mat3_matmul_eig(SVt, SV, out);
+    return 1;
+}
+/* invSigma^T * aniso_inv * invSigma of SE::getInvCovMtx / sparseConvNoiseOneOverSecondDerivative (GPF.cpp:716-726, 776-786) */
+static void se_sandwich(const oracle_medium *m, int isIsotropic, int divideGlobal, float globalScale, const float *aniso_inv, float *out)
+{
+    float iS[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, iSt[9], T[9];
+    if (!isIsotropic) {
+        if (!m->P.use_aniso_mtx) {
+            iS[0] = m->l_aniso_inv[0]; iS[4] = m->l_aniso_inv[1]; iS[8] = m->l_aniso_inv[2];
+        } else {
+            memcpy(iS, m->w2l, sizeof iS);
+        }
+        if (divideGlobal)
+            for (int i = 0; i < 9; ++i) iS[i] /= globalScale;
+    }
+    mat3_transpose(iS, iSt);
+    mat3_matmul_eig(iSt, aniso_inv, T);
+    mat3_matmul_eig(T, iS, out);
+}
+/* SE::getInvCovMtx, GPF.cpp:774-802 (aniso_inv null without an aniso field) */
+static void se_inv_cov_mtx(const oracle_medium *m, int isCov, int isIsotropic, float globalScale, float localScale, const float *aniso_inv, float *out)
 {
     float A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (!isIsotropic) {
+    if (aniso_inv) {
+        se_sandwich(m, isIsotropic, 1, globalScale, aniso_inv, A);
+    } else if (!isIsotropic) {
         if (!m->P.use_aniso_mtx) {
             A[0] = m->l_aniso_inv[0] * m->l_aniso_inv[0];
             A[4] = m->l_aniso_inv[1] * m->l_aniso_inv[1];
@@ -650,8 +689,10 @@ static v4f cov_splat3d(const oracle_medium *m, v3f pa, v3f pb, int isCov, int is
     if (m->P.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
         return other_splat3d(m, v3_sub(pa, pb));      /* StationaryCovariance forwards a - b, GPF.hpp:1607-1612 */
     float localScale = cov_ns_scale(m, p_world);
-    float A[9];
-    se_inv_cov_mtx(m, isCov, isIso, globalScale, localScale, A);
+    float A[9], an[9], an_inv[9];
+    int has = cov_ns_aniso3d(m, p_world, an);
+    if (has) eig_inverse3(an, an_inv);
+    se_inv_cov_mtx(m, isCov, isIso, globalScale, localScale, has ? an_inv : NULL, A);
     v3f ab = v3_sub(pa, pb);
     float val = se_splat3d_val(ab, A);
     v3f g = se_splat3d_grad(ab, A);
@@ -667,8 +708,10 @@ static v4f cov_splat3d_grad(const oracle_medium *m, v3f pa, v3f pb, v3f coeff, i
         return v4_add(v4_add(v4_scale(vx, coeff.x), v4_scale(vy, coeff.y)), v4_scale(vz, coeff.z));
     }
     float localScale = cov_ns_scale(m, p_world);
-    float A[9], H[9];
-    se_inv_cov_mtx(m, isCov, isIso, globalScale, localScale, A);
+    float A[9], H[9], an[9], an_inv[9];
+    int has = cov_ns_aniso3d(m, p_world, an);
+    if (has) eig_inverse3(an, an_inv);
+    se_inv_cov_mtx(m, isCov, isIso, globalScale, localScale, has ? an_inv : NULL, A);
     v3f ab = v3_sub(pa, pb);
     v3f g = se_splat3d_grad(ab, A);
     se_splat3d_hess(ab, A, H);
@@ -718,11 +761,16 @@ static void cov_splat1d(const oracle_medium *m, float pQuery, float pCenter, v3f
 /* covarianceKernel1D*, GPF.cpp:587-602, GPF.hpp:1622-1640, GPF.cpp:1302-1331 */
 static float cov_cov1d_scale(const oracle_medium *m, v3f pq, v3f pc) { return m->P.nonstationary ? cov_splat_cov_1d(m, pq, pc) : 1.0f; }
 
-/* SE::sparseConvNoiseOneOverSecondDerivative, GPF.cpp:713-739 (aniso_inv null) */
-static void cov_one_over_second_derivative(const oracle_medium *m, int isIsotropic, float *out)
+/* SE::sparseConvNoiseOneOverSecondDerivative, GPF.cpp:713-739, reached through NonstationaryCovariance (GPF.cpp:1239-1243),
+ * which hands over the aniso matrix at p_world (inverted inside) */
+static void cov_one_over_second_derivative(const oracle_medium *m, v3f p_world, int isIsotropic, float *out)
 {
     float A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (!isIsotropic) {
+    float an[9], an_inv[9];
+    if (cov_ns_aniso3d(m, p_world, an)) {
+        eig_inverse3(an, an_inv);
+        se_sandwich(m, isIsotropic, 0, 1.f, an_inv, A);
+    } else if (!isIsotropic) {
         if (!m->P.use_aniso_mtx) {
             A[0] = m->l_aniso_inv[0] * m->l_aniso_inv[0];
             A[4] = m->l_aniso_inv[1] * m->l_aniso_inv[1];
@@ -1138,7 +1186,7 @@ static void conditioning3d(realization *r, v3f p, v3f rayDir, float targetVal, v
             v3f ray_dir_iso = v3_normalized(cov_pos_world_to_local(m, rayDir, 1.0f));
             frame coord = frame_from_normal(ray_dir_iso);
             gs_iso = frame_to_local(&coord, gs_iso);
-            cov_one_over_second_derivative(m, 1, S);
+            cov_one_over_second_derivative(m, p, 1, S);
             v3f g = eig_matvec(S, gs_iso);
             if (m->multi_res) {
                 float d = ksi[2] / ksi[0] + ksi[3] / ksi[1];
@@ -1149,7 +1197,7 @@ static void conditioning3d(realization *r, v3f p, v3f rayDir, float targetVal, v
             }
             r->c3.gradient_scale[0] = g.x; r->c3.gradient_scale[1] = g.y; r->c3.gradient_scale[2] = g.z;
         } else {
-            cov_one_over_second_derivative(m, 0, S);
+            cov_one_over_second_derivative(m, p, 0, S);
             v3f g = eig_matvec(S, delta);
             if (m->multi_res) {
                 float d = ksi[2] / (ksi[0] * ksi[0]) + ksi[3] / (ksi[1] * ksi[1]);
@@ -1632,8 +1680,8 @@ void oracle_default_params(gpis_params *p)
     p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          /* GPF.hpp:697-698 */
     p->matern_v = 0.5f; p->gabor_a_inv = 1.f; p->gabor_f_inv = 1.f; p->gabor_omega[0] = 1.f;   /* GPF.hpp:1964, 2041, 2079 */
     {
-        gpis_ramp *ramps[3] = {&p->var, &p->mean_color, &p->mean_emission};
-        for (int i = 0; i < 3; ++i) {
+        gpis_ramp *ramps[4] = {&p->var, &p->mean_color, &p->mean_emission, &p->aniso_field};
+        for (int i = 0; i < 4; ++i) {
             ramps[i]->min = 1.; ramps[i]->max = 500.; ramps[i]->start = 0.; ramps[i]->end = 1.;
             ramps[i]->min2 = 1.; ramps[i]->max2 = 500.; ramps[i]->start2 = 0.; ramps[i]->end2 = 1.;
         }
@@ -1657,6 +1705,11 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
         (params->mean_emission.enabled && (params->mean_emission.type < 0 || params->mean_emission.type > 3)))
         return fail("invalid procedural noise type");
     if (params->var.enabled && !params->nonstationary) return fail("a var field needs the proc_nonstationary wrapper");
+    if (params->aniso_field.enabled) {
+        if (params->aniso_field.type < 0 || params->aniso_field.type > 3) return fail("invalid procedural noise type");
+        if (!params->nonstationary) return fail("an aniso field needs the proc_nonstationary wrapper");
+        if (params->sampling_1d) return fail("an aniso field is built for 3D sampling only");
+    }
     if (params->kernel_type < 0 || params->kernel_type > 3) return fail("invalid kernel type");
     if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
         if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 2.5f)

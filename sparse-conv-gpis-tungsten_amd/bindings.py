@@ -49,6 +49,7 @@ PARAMS = np.dtype([
     ("ls_min2", "<f8"), ("ls_max2", "<f8"), ("ls_start2", "<f8"), ("ls_end2", "<f8"),
     ("var", RAMP), ("mean_color", RAMP), ("mean_emission", RAMP),
     ("kernel_type", "<i4"), ("matern_v", "<f4"), ("gabor_a_inv", "<f4"), ("gabor_f_inv", "<f4"), ("gabor_omega", "<f4", 3), ("_pad2", "<i4"),
+    ("aniso_field", RAMP),
 ], align=True)
 
 RAY_IN = np.dtype([
@@ -150,7 +151,7 @@ def default_params():
     p["local_scale"] = 3.0
     p["ls_min"], p["ls_max"], p["ls_start"], p["ls_end"] = 1.0, 500.0, 0.0, 1.0
     p["ls_min2"], p["ls_max2"], p["ls_start2"], p["ls_end2"] = 1.0, 500.0, 0.0, 1.0
-    for key in ("var", "mean_color", "mean_emission"):
+    for key in ("var", "mean_color", "mean_emission", "aniso_field"):
         p[key]["min"], p[key]["max"], p[key]["start"], p[key]["end"] = 1.0, 500.0, 0.0, 1.0
         p[key]["min2"], p[key]["max2"], p[key]["start2"], p[key]["end2"] = 1.0, 500.0, 0.0, 1.0
     for key in ("mean", "mean_additional"):

@@ -71,6 +71,7 @@ struct DevModel {
     double ls_min, ls_max, ls_scale, ls_offset, ls_log_min2, ls_log_max2;
     DevRamp ls;                   // the same "ls" field in the general form (bottom_top_left_right needs the second ramp)
     DevRamp var, color, emission; // "var" (GPF.cpp:1638-1641), mean "color" / "emission" (GPF.hpp:849-857)
+    DevRamp aniso;                // "aniso" angle field (GPF.cpp:1678-1689)
     float sigma_raw;              // the stationary kernel's sigma (sparseConvNoiseAmplitude() of GPF.cpp:711)
     // Matérn / Gabor kernels (GPF.cpp:866-1214): world-space 3D sampling only; radius_world / norm3d_world hold their constants
     int32_t kernel_type;          // gpis_kernel_type
@@ -531,6 +532,7 @@ GPIS_DEV double lerp_d(double a, double b, double ratio) { return a * (1.0 - rat
 // (not an inline namespace: ADL must not see them from inside the specialised namespaces).
 #define GPIS_PATH_NS generic
 #define GPIS_FLAG_other_kernels(M) ((M).kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
+#define GPIS_FLAG_aniso_field(M) ((M).aniso.enabled)
 #define GPIS_FLAG_sampling_1d(M) ((M).sampling_1d)
 #define GPIS_FLAG_multi_res(M) ((M).multi_res)
 #define GPIS_FLAG_nonstationary(M) ((M).nonstationary)
@@ -542,6 +544,7 @@ namespace gpis { using namespace generic; }
 // 1D sampling along the ray (config C2)
 #define GPIS_PATH_NS spec_1d
 #define GPIS_FLAG_other_kernels(M) 0
+#define GPIS_FLAG_aniso_field(M) 0
 #define GPIS_FLAG_sampling_1d(M) 1
 #define GPIS_FLAG_multi_res(M) ((M).multi_res)
 #define GPIS_FLAG_nonstationary(M) ((M).nonstationary)
@@ -552,6 +555,7 @@ namespace gpis { using namespace generic; }
 // 3D sampling, stationary kernel (config C0 and its per-path variants, C1 without the fast path)
 #define GPIS_PATH_NS spec_3d
 #define GPIS_FLAG_other_kernels(M) 0
+#define GPIS_FLAG_aniso_field(M) 0
 #define GPIS_FLAG_sampling_1d(M) 0
 #define GPIS_FLAG_multi_res(M) 0
 #define GPIS_FLAG_nonstationary(M) 0
@@ -562,6 +566,7 @@ namespace gpis { using namespace generic; }
 // 3D sampling, non-stationary length scale on the multi-resolution grid (config C3)
 #define GPIS_PATH_NS spec_3d_multires
 #define GPIS_FLAG_other_kernels(M) 0
+#define GPIS_FLAG_aniso_field(M) 0
 #define GPIS_FLAG_sampling_1d(M) 0
 #define GPIS_FLAG_multi_res(M) 1
 #define GPIS_FLAG_nonstationary(M) 1

@@ -261,6 +261,8 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
     };
     M.ls = make_ramp(M.nonstationary, P.ls_ramp_type, P.ls_min, P.ls_max, P.ls_start, P.ls_end, P.ls_min2, P.ls_max2, P.ls_start2, P.ls_end2);
     M.var = make_ramp(P.var.enabled != 0, P.var.type, P.var.min, P.var.max, P.var.start, P.var.end, P.var.min2, P.var.max2, P.var.start2, P.var.end2);
+    M.aniso = make_ramp(P.aniso_field.enabled != 0, P.aniso_field.type, P.aniso_field.min, P.aniso_field.max, P.aniso_field.start, P.aniso_field.end,
+                        P.aniso_field.min2, P.aniso_field.max2, P.aniso_field.start2, P.aniso_field.end2);
     M.color = make_ramp(P.mean_color.enabled != 0, P.mean_color.type, P.mean_color.min, P.mean_color.max, P.mean_color.start, P.mean_color.end,
                         P.mean_color.min2, P.mean_color.max2, P.mean_color.start2, P.mean_color.end2);
     M.emission = make_ramp(P.mean_emission.enabled != 0, P.mean_emission.type, P.mean_emission.min, P.mean_emission.max, P.mean_emission.start, P.mean_emission.end,
@@ -1127,7 +1129,7 @@ extern "C" void gpis_default_params(gpis_params *p)
     p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;
     p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          // GPF.hpp:694-699
     p->matern_v = 0.5f; p->gabor_a_inv = 1.f; p->gabor_f_inv = 1.f; p->gabor_omega[0] = 1.f;   // GPF.hpp:1964, 2041, 2079
-    gpis_ramp *ramps[3] = {&p->var, &p->mean_color, &p->mean_emission};
+    gpis_ramp *ramps[4] = {&p->var, &p->mean_color, &p->mean_emission, &p->aniso_field};
     for (gpis_ramp *r : ramps) { r->min = 1.; r->max = 500.; r->start = 0.; r->end = 1.; r->min2 = 1.; r->max2 = 500.; r->start2 = 0.; r->end2 = 1.; }
     p->mean.type = GPIS_MEAN_SPHERICAL; p->mean.radius = 1.f;
     p->mean.scale = 1.f; p->mean.min = -FLT_MAX; p->mean.dir[0] = 1.;
@@ -1150,6 +1152,11 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         for (const gpis_ramp *r : ramps)
             if (r->enabled && (r->type < 0 || r->type > 3)) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type (sandstone / rust are outside the built scope)");
         if (params->var.enabled && !params->nonstationary) return set_err(GPIS_ERR_INVALID_ARG, "a \"var\" field needs the proc_nonstationary wrapper");
+        if (params->aniso_field.enabled) {
+            if (params->aniso_field.type < 0 || params->aniso_field.type > 3) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type (sandstone / rust are outside the built scope)");
+            if (!params->nonstationary) return set_err(GPIS_ERR_INVALID_ARG, "an \"aniso\" field needs the proc_nonstationary wrapper");
+            if (params->sampling_1d) return set_err(GPIS_ERR_INVALID_ARG, "an \"aniso\" field is built for 3D sampling only (GPF.cpp:1691-1727 are outside the built scope)");
+        }
     }
     if (params->kernel_type < 0 || params->kernel_type > 3) return set_err(GPIS_ERR_INVALID_ARG, "invalid kernel type");
     if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
@@ -1422,7 +1429,7 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
 
 // ---- persistent march launch (per-path media) ---------------------------------------------------------------
 // the lattice sums of gpis_persist.inc have a diagonal kernel matrix: every medium except world-space 3D with a full anisoMtx
-static bool persist_supported(const DevModel &H) { return H.sampling_1d || H.iso3d || !H.use_aniso_mtx; }
+static bool persist_supported(const DevModel &H) { return !H.aniso.enabled && (H.sampling_1d || H.iso3d || !H.use_aniso_mtx); }
 // sideways (lane = impulse) evaluation pays while at most this many lanes of a wave have a job: lockstep costs
 // 27 n g instructions per round whatever the number of jobs, one sideways job ~20.6 cells x (c0 + c1 n)
 // (g = 61 generator, c0 = 135, c1 = 0.31: counted on the gfx950 ISA of these loops)
@@ -1515,7 +1522,7 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
         k_sample_distance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
     else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL)
         k_sample_distance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
-    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
+    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid && !H.aniso.enabled)
         k_sample_distance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
     else
         k_sample_distance<generic::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
@@ -1560,7 +1567,7 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
         k_transmittance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
     else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL)
         k_transmittance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
-    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
+    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid && !H.aniso.enabled)
         k_transmittance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
     else
         k_transmittance<generic::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);

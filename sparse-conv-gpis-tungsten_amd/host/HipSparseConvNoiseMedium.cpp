@@ -273,8 +273,7 @@ void HipSparseConvNoiseMedium::fromJson(const std::string &json)
                     getNum(*ls, "end2", p.ls_end2);
                 }
                 if (const JValue *var = c->get("var")) readRamp(*var, p.var);          // GPF.cpp:1593-1595
-                if (c->get("aniso"))
-                    throw std::runtime_error("proc_nonstationary 'aniso' field is outside the built scope");
+                if (const JValue *an = c->get("aniso")) readRamp(*an, p.aniso_field);  // GPF.cpp:1600-1602
             } else {
                 throw std::runtime_error("Unsupported covariance type: '" + type + "'");
             }

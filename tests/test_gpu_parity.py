@@ -498,6 +498,53 @@ def test_multi_resolution_nonstationary(env, iso, oned):
     assert _close(got["t"][same], want["t"][same], 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("iso,multires,ctx", [(0, 0, "RENEWAL_PLUS"), (1, 0, "RENEWAL_PLUS"), (1, 1, "RENEWAL"), (0, 1, "NONE")])
+def test_aniso_field(env, iso, multires, ctx):
+    """proc_nonstationary "aniso" field (GPF.cpp:1600-1602, 1678-1689, 716-726, 776-786, 1245-1249): a
+    full kernel matrix per evaluation, the conditioning's second-derivative matrix and the 1.5 x kernel radius.  The angle goes
+    through the device's log / exp / sinf / cosf: toleranced.  With 1D sampling the medium is refused by both sides."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C3")
+    params["impulse_density"] = 12
+    params["isotropic_3d_sampling"] = iso
+    params["multi_resolution_grid"] = multires
+    params["correlation_context"] = getattr(pkg.CTX, ctx)
+    params["aniso"] = (1.0, 0.8, 1.25)
+    params["aniso_field"]["enabled"], params["aniso_field"]["type"] = 1, 0
+    params["aniso_field"]["min"], params["aniso_field"]["max"] = 0.1, 0.9
+    params["aniso_field"]["start"], params["aniso_field"]["end"] = -1.0, 1.0
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    d_g, d_o = med.derived(), orc.derived()
+    assert d_g["kernel_radius_world"] == d_o["kernel_radius_world"] and d_g["kernel_radius_iso"] == d_o["kernel_radius_iso"]
+    q = _queries(pkg, 1024, 91)
+    assert _close(med.eval_value(q)[0], orc.eval_value(q)[0], 1e-4, 1e-5)
+    assert _close(med.eval_gradient(q), orc.eval_gradient(q), 2e-4, 2e-4)
+    if ctx != "NONE":
+        tv = np.linspace(-0.05, 0.05, len(q)).astype(np.float32)
+        tg = np.stack([np.cos(np.arange(len(q))), np.sin(np.arange(len(q))), np.ones(len(q))], axis=1).astype(np.float32) * 3
+        c_g, c_o = med.conditioning(q, tv, tg), orc.conditioning(q, tv, tg)
+        for f in ("value_scale", "gradient_scale", "ray_origin"):
+            assert _close(c_g[f], c_o[f], 5e-4, 5e-4), f
+    scene = ob.default_scene_s(128, 72, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    want = orc.sample_distance(rays, want_coeff=True)
+    sh = shadow_rays_from(ob, scene, rays, us, want[0])
+    batch = np.concatenate([rays, sh])
+    got, want = med.sample_distance(batch), orc.sample_distance(batch)
+    flips = int((got["exited"] != want["exited"]).sum())
+    assert flips <= max(1, len(batch) // 300), "hit/miss flips: %d of %d" % (flips, len(batch))
+    same = got["exited"] == want["exited"]
+    assert _close(got["t"][same], want["t"][same], 1e-4, 1e-4)
+    assert (med.transmittance(batch) != orc.transmittance(batch)).sum() <= max(1, len(batch) // 300)
+    bad = params.copy()
+    bad["sampling_1d"] = 1
+    bad["isotropic_3d_sampling"] = 1
+    with pytest.raises(RuntimeError):
+        pkg.Medium(bad)
+    with pytest.raises(Exception):
+        ob.Oracle(bad)
+
+
 @pytest.mark.parametrize("multires", [1, 0])
 def test_variance_field_btlr_color_emission(env, multires):
     """The rest of the proc_nonstationary wrapper and of the mean: a "var" field (amplitude = var(p) * sigma,
