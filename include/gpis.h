@@ -176,7 +176,38 @@ typedef struct gpis_params {
      *     (getNonstationaryAniso3D, GPF.cpp:1678-1689).  Built for 3D sampling (world and isotropic-ray space); with 1D sampling
      *     the medium is refused (getNonstationaryAniso1D / ...CovSplatCov1D, GPF.cpp:1691-1727, are outside the built scope). --- */
     gpis_ramp aniso_field;
+    /* --- FunctionSpaceGaussianProcessMedium (FunctionSpaceGaussianProcessMedium.cpp:34-43): read by the
+     *     gpis_fs_* entry points only.  "skip_space" = 0 and "step_size_cov" (dead code in the reference, :98-106) are not carried. --- */
+    int32_t fs_sample_points;        /* "sample_points" (2 .. GPIS_FS_MAX_POINTS; the reference's default is 32) */
+    int32_t _pad3;
+    double fs_step_size;             /* "step_size" of the function-space medium (0 = the whole segment in one batch of points) */
 } gpis_params;
+
+/* The function-space comparison path (FunctionSpaceGaussianProcessMedium.cpp:58-282): the field is sampled at `sample_points`
+ * positions of the segment from the multivariate normal the GP prior (or its conditional, given the previous segment's
+ * values) defines there — covariance build, pseudo-inverse through a symmetric eigen-decomposition, Cholesky (or the
+ * eigen square root when it fails), GaussianProcess.cpp:590-753, Gaussian.cpp:121-232.
+ * Built for: squared-exponential covariance in its GP form (sigma^2 exp(-d^T diag(aniso) d / (2 l^2)), GPF.hpp:1602-1605,
+ * GPF.cpp:770-772), the analytic means, all four correlation contexts, normal sampling "ConditionedGaussian".
+ *
+ * gpis_fs_state = the caller-owned MediumState part this medium adds: state.gpContext (GPContextFunctionSpace,
+ * GaussianProcessMedium.hpp:23-33: points, derivative kinds and the GPRealNodeValues) and the path's PathSampleGenerator
+ * (a PCG32 stream, UniformPathSampler), from which the medium draws an unbounded number of variates.  It is a VALUE: a shadow
+ * segment works on a copy and never alters the path's context (in the reference the copy of MediumState shares the
+ * GPRealNode, which applyMemory mutates in place, GaussianProcess.cpp:134-168). */
+#define GPIS_FS_MAX_POINTS 64
+#define GPIS_FS_MAX_CTX 66
+typedef struct gpis_fs_state {
+    uint64_t sampler_state;          /* PCG32 state (UniformSampler.hpp:41-75) */
+    int32_t has_context;             /* state.gpContext != nullptr */
+    int32_t is_intersect;            /* GPRealNodeValues::_isIntersect */
+    int32_t n_points;                /* ctxt->points.size() */
+    int32_t n_values;                /* ctxt->values rows (differs from n_points only transiently) */
+    double sampled_grad[3];          /* GPRealNodeValues::_sampledGrad */
+    double points[GPIS_FS_MAX_CTX][3];
+    double values[GPIS_FS_MAX_CTX];
+    int32_t derivs[GPIS_FS_MAX_CTX]; /* 0 = Derivative::None, 1 = Derivative::First */
+} gpis_fs_state;
 
 /*
  * One ray segment handed to Medium::sampleDistance / Medium::transmittance
@@ -333,6 +364,12 @@ int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float
  * stores in MediumSample.emission.  color3 / emission3: n xyz triples of float; either may be NULL. */
 int gpis_mean_color_emission_batch(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3, void *stream);
 int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3);
+
+/* Medium::sampleDistance / transmittance of the function-space medium (GaussianProcessMedium.cpp:221-393 over
+ * FunctionSpaceGaussianProcessMedium::intersectGP / sampleGradient).  rays[i].u_jitter is not used (every variate comes from
+ * states[i].sampler_state); states are read and written in place (device pointers). */
+int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream);
+int gpis_fs_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible, void *stream);
 
 /* Bit-exact primitives (MathUtil.hpp:179-224, UniformSampler.hpp:41-75, BitManip.hpp:47-50):
  * out[i] = xxhash32 of `arity` (1..4) words at words[i*arity..]; and the PCG32 stream

@@ -1679,6 +1679,7 @@ void oracle_default_params(gpis_params *p)
     p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;              /* GPF.hpp:694-695 */
     p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          /* GPF.hpp:697-698 */
     p->matern_v = 0.5f; p->gabor_a_inv = 1.f; p->gabor_f_inv = 1.f; p->gabor_omega[0] = 1.f;   /* GPF.hpp:1964, 2041, 2079 */
+    p->fs_sample_points = 32; p->fs_step_size = 0.;                                  /* FunctionSpace...cpp:24-26 */
     {
         gpis_ramp *ramps[4] = {&p->var, &p->mean_color, &p->mean_emission, &p->aniso_field};
         for (int i = 0; i < 4; ++i) {
@@ -1994,6 +1995,8 @@ int oracle_nee_grad_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, f
 }
 
 /* MeanFunction::color / emission, GPF.hpp:849-857 (1 / 0 without the field; ramp noises have three equal components) */
+#include "gpis_fs_oracle.inc"
+
 int oracle_mean_color_emission(oracle_medium *m, size_t n, const double *p3, float *color3, float *emission3)
 {
     if (!m || (n && !p3)) return fail("null argument");

@@ -47,6 +47,13 @@ int oracle_conditioning_batch(oracle_medium *m, size_t n, const gpis_query *q, c
 int oracle_nee_pdf_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, float *pdf);
 int oracle_nee_grad_batch(oracle_medium *m, size_t n, const gpis_nee_query *q, float *grad3);
 
+/* function-space comparison path, host pointers; states are read and written in place */
+int oracle_fs_sample_distance_batch(oracle_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out);
+int oracle_fs_transmittance_batch(oracle_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible);
+void oracle_fs_eigh(int n, double *A_colmajor, double *w);
+void oracle_fs_norm_transform(int n, const double *S_colmajor, double *T_colmajor);
+double oracle_fs_cov(oracle_medium *m, int da, int db, const double *a, const double *b, const double *dirA, const double *dirB);
+
 int oracle_mean_color_emission(oracle_medium *m, size_t n, const double *p3, float *color3, float *emission3);
 int oracle_xxhash32_batch(size_t n, int arity, const uint32_t *words, uint32_t *out);
 int oracle_pcg32_stream_batch(size_t n, const uint64_t *state, uint32_t count, uint32_t *out);

@@ -132,6 +132,45 @@ class Oracle:
         assert self.lib.oracle_nee_grad_batch(self.h, q.shape[0], _p(q), _p(out)) == 0
         return out
 
+    # ---- function-space comparison path: states are updated in place and returned
+    def fs_sample_distance(self, rays, states):
+        rays = np.ascontiguousarray(rays, dtype=RAY_IN)
+        states = np.ascontiguousarray(states, dtype=_T.FS_STATE).copy()
+        out = np.zeros(rays.shape[0], dtype=SEG_OUT)
+        rc = self.lib.oracle_fs_sample_distance_batch(self.h, rays.shape[0], _p(rays), _p(states), _p(out))
+        if rc != 0:
+            raise RuntimeError("oracle_fs_sample_distance_batch failed: %d" % rc)
+        return out, states
+
+    def fs_transmittance(self, rays, states):
+        rays = np.ascontiguousarray(rays, dtype=RAY_IN)
+        states = np.ascontiguousarray(states, dtype=_T.FS_STATE).copy()
+        vis = np.zeros(rays.shape[0], dtype=np.uint8)
+        rc = self.lib.oracle_fs_transmittance_batch(self.h, rays.shape[0], _p(rays), _p(states), _p(vis))
+        if rc != 0:
+            raise RuntimeError("oracle_fs_transmittance_batch failed: %d" % rc)
+        return vis, states
+
+    def fs_eigh(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        n = a.shape[0]
+        m = np.asfortranarray(a).copy(order="F")
+        w = np.zeros(n, dtype=np.float64)
+        self.lib.oracle_fs_eigh(n, m.ctypes.data_as(ctypes.c_void_p), _p(w))
+        return w, m
+
+    def fs_norm_transform(self, s):
+        s = np.asfortranarray(np.asarray(s, dtype=np.float64))
+        t = np.zeros_like(s, order="F")
+        self.lib.oracle_fs_norm_transform(s.shape[0], s.ctypes.data_as(ctypes.c_void_p), t.ctypes.data_as(ctypes.c_void_p))
+        return t
+
+    def fs_cov(self, da, db, a, b, dir_a, dir_b):
+        f = self.lib.oracle_fs_cov
+        f.restype = ctypes.c_double
+        v = [np.ascontiguousarray(x, dtype=np.float64) for x in (a, b, dir_a, dir_b)]
+        return f(self.h, int(da), int(db), *[_p(x) for x in v])
+
     def mean_color_emission(self, points):
         p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         col = np.zeros((p.shape[0], 3), dtype=np.float32)

@@ -50,6 +50,13 @@ PARAMS = np.dtype([
     ("var", RAMP), ("mean_color", RAMP), ("mean_emission", RAMP),
     ("kernel_type", "<i4"), ("matern_v", "<f4"), ("gabor_a_inv", "<f4"), ("gabor_f_inv", "<f4"), ("gabor_omega", "<f4", 3), ("_pad2", "<i4"),
     ("aniso_field", RAMP),
+    ("fs_sample_points", "<i4"), ("_pad3", "<i4"), ("fs_step_size", "<f8"),
+], align=True)
+
+FS_MAX_POINTS, FS_MAX_CTX = 64, 66
+FS_STATE = np.dtype([
+    ("sampler_state", "<u8"), ("has_context", "<i4"), ("is_intersect", "<i4"), ("n_points", "<i4"), ("n_values", "<i4"),
+    ("sampled_grad", "<f8", 3), ("points", "<f8", (FS_MAX_CTX, 3)), ("values", "<f8", FS_MAX_CTX), ("derivs", "<i4", FS_MAX_CTX),
 ], align=True)
 
 RAY_IN = np.dtype([
@@ -128,6 +135,7 @@ _EXPECTED_SIZES = {
     "gpis_seg_out": SEG_OUT.itemsize, "gpis_cond_coeff": COND_COEFF.itemsize, "gpis_query": QUERY.itemsize,
     "gpis_nee_query": NEE_QUERY.itemsize, "gpis_derived": DERIVED.itemsize, "gpis_scene_s": SCENE_S.itemsize,
     "gpis_surface_s": SURFACE_S.itemsize, "gpis_ramp": RAMP.itemsize,
+    "gpis_fs_state": FS_STATE.itemsize,
 }
 assert RAY_IN.itemsize == 128 and SEG_OUT.itemsize == 96 and COND_COEFF.itemsize == 32
 assert QUERY.itemsize == 96 and NEE_QUERY.itemsize == 96
@@ -138,6 +146,7 @@ def default_params():
     p = np.zeros((), dtype=PARAMS)
     p["abi_version"] = 2
     p["matern_v"], p["gabor_a_inv"], p["gabor_f_inv"], p["gabor_omega"] = 0.5, 1.0, 1.0, (1.0, 0.0, 0.0)
+    p["fs_sample_points"], p["fs_step_size"] = 32, 0.0
     p["step_size"] = 0.01
     p["min_step"] = 8
     p["impulse_density"] = 3.0

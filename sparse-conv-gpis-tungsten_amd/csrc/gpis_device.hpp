@@ -539,7 +539,7 @@ GPIS_DEV double lerp_d(double a, double b, double ratio) { return a * (1.0 - rat
 #define GPIS_FLAG_multi_resolution_grid(M) ((M).multi_resolution_grid)
 #define GPIS_FLAG_activate_conditioning(M) ((M).activate_conditioning)
 #include "gpis_path.inc"
-namespace gpis { using namespace generic; }
+// (no using-directive: every user names its instance — fast / guided / wavefront kernels spec_3d, the single-query entries generic)
 
 // 1D sampling along the ray (config C2)
 #define GPIS_PATH_NS spec_1d

@@ -131,7 +131,7 @@ constexpr int kFastBlock = 64;          // one wave per workgroup
 GPIS_DEV V4 noise3d_per_lane(const DevModel &M, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
 {
     float A[9] = {A0, 0.f, 0.f, 0.f, A1, 0.f, 0.f, 0.f, A2};
-    return noise3d(M, p, seed, R, A, true);
+    return spec_3d::noise3d(M, p, seed, R, A, true);
 }
 
 // One cooperative noise3D (SCN.cpp:362-395) for the lanes with `active` set.
@@ -523,10 +523,10 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &ld
         V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p, M.seed, R, A0, A1, A2, split);
         return nz / M.norm3d_world;
     }
-    V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
+    V3 p_iso_ray = to_local(coord, spec_3d::cov_pos_w2l(M, p, 1.0f));
     V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f, split);
     if (GRAD) {
-        V3 gw = cov_grad_l2w(M, to_global(coord, v3(nz.gx, nz.gy, nz.gz)), 1.0f);
+        V3 gw = spec_3d::cov_grad_l2w(M, to_global(coord, v3(nz.gx, nz.gy, nz.gz)), 1.0f);
         return v4(nz.v, gw.x, gw.y, gw.z) / M.norm3d_iso;
     }
     return v4(nz.v / M.norm3d_iso, 0.f, 0.f, 0.f);
@@ -558,7 +558,7 @@ GPIS_DEV float solo_evaluate_value(const DevModel &M, const FastTable &T, FastLd
         nv = (PACKED ? solo_noise3d_value_packed(M, T, lds, src, p, M.seed, M.radius_world, A0, A1, A2)
                      : solo_noise3d_value(M, T, lds, src, p, M.seed, M.radius_world, A0, A1, A2)) / M.norm3d_world;
     } else {
-        V3 p_iso_ray = to_local(coord, cov_pos_w2l(M, p, 1.0f));
+        V3 p_iso_ray = to_local(coord, spec_3d::cov_pos_w2l(M, p, 1.0f));
         nv = (PACKED ? solo_noise3d_value_packed(M, T, lds, src, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f)
                      : solo_noise3d_value(M, T, lds, src, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f)) / M.norm3d_iso;
     }
@@ -676,7 +676,7 @@ GPIS_DEV void fast_march(const DevModel &M, const FastTable &T, FastLds &lds, bo
         step_size = M.step_size;
     Frame coord{};
     if (M.iso3d)
-        coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
+        coord = frame_from_normal(normalized(spec_3d::cov_pos_w2l(M, dir, 1.0f)));
 
     int phase = PH_INIT;
     bool early_ok = false;         // maxT == 0 shortcut

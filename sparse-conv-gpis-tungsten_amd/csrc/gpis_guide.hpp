@@ -240,7 +240,7 @@ GPIS_DEV V3 grid_point(const DevModel &M, const GuideField &F, V3 p, const Frame
 {
     if (!M.iso3d)
         return p / F.R;
-    return to_local(coord, cov_pos_w2l(M, p, 1.0f)) / F.R;
+    return to_local(coord, spec_3d::cov_pos_w2l(M, p, 1.0f)) / F.R;
 }
 
 // certified sign of the field at world point p: +1 / -1, or 0 when the guide cannot decide
@@ -340,7 +340,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         if (M.iso3d) {
             V3 d = dir;
             asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
-            c = frame_from_normal(normalized(cov_pos_w2l(M, d, 1.0f)));
+            c = frame_from_normal(normalized(spec_3d::cov_pos_w2l(M, d, 1.0f)));
         }
         return c;
     };
@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(kFastBlock) k_guide_raycheck(const DevModel *_
         step_size = M.step_size;
     Frame coord{};
     if (M.iso3d)
-        coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
+        coord = frame_from_normal(normalized(spec_3d::cov_pos_w2l(M, dir, 1.0f)));
     const GuideRay gr = guide_ray(M, F, pos, dir, coord);
     double t = (double)(nearT + step_size * u);
     unsigned long long certified = 0, bad = 0;

@@ -76,7 +76,7 @@ GPIS_DEV void guided_march_range(const DevModel &M, const FastTable &T, const Gu
         if (M.iso3d) {
             V3 d = dir;
             asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
-            c = frame_from_normal(normalized(cov_pos_w2l(M, d, 1.0f)));
+            c = frame_from_normal(normalized(spec_3d::cov_pos_w2l(M, d, 1.0f)));
         }
         return c;
     };
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_guided_range_grad
     }
     Frame coord{};
     if (M.iso3d)
-        coord = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
+        coord = frame_from_normal(normalized(spec_3d::cov_pos_w2l(M, dir, 1.0f)));
     V3d rdn = to_d(dir);
     { double inv = 1.0 / length_d(rdn); rdn.x *= inv; rdn.y *= inv; rdn.z *= inv; }
     const V3 pgq = to_f(ray_at(to_d(pos), rdn, t));

@@ -370,6 +370,7 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
         D.norm1d = M.norm1d;
     } else {
         float ls = (float)((double)1.0f * (M.multi_resolution_grid ? 1.0 : (double)M.ls_maxval));
+        ls *= M.aniso.enabled ? 1.5f : 1.f;          // sparseConvNoiseMaxAnisotropyScale(), GPF.cpp:1743-1747
         D.kernel_radius_world = M.kernel_scale * ls * M.mtx_factor;
         D.kernel_radius_iso = M.kernel_scale;
         D.norm3d_world = 0.f; D.norm3d_iso = 0.f; D.norm1d = 0.f;   // position dependent: not constants of the medium
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(kBlock) k_eval_value(const DevModel *__restric
         gpis_query qq = q[i];
         r.c = qq.coeff;
         int id;
-        value[i] = evaluate_value(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq), id);
+        value[i] = generic::evaluate_value(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq), id);
         if (gp_id) gp_id[i] = id;
     }
     flush_counters(cnt, r.n_eval, 0);
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(kBlock) k_eval_gradient(const DevModel *__rest
     if (i < n) {
         gpis_query qq = q[i];
         r.c = qq.coeff;
-        V3 g = evaluate_gradient(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), qq.t_segment, v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq));
+        V3 g = generic::evaluate_gradient(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), qq.t_segment, v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq));
         grad3[3 * i] = g.x; grad3[3 * i + 1] = g.y; grad3[3 * i + 2] = g.z;
     }
     flush_counters(cnt, r.n_eval, 0);
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(kBlock) k_conditioning(const DevModel *__restr
     Realization r{};
     if (i < n) {
         gpis_query qq = q[i];
-        conditioning(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), tv[i], v3(tg[3 * i], tg[3 * i + 1], tg[3 * i + 2]), info_of(qq));
+        generic::conditioning(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), tv[i], v3(tg[3 * i], tg[3 * i + 1], tg[3 * i + 2]), info_of(qq));
         gpis_cond_coeff c = r.c;
         c.n_evals = r.n_eval;
         co[i] = c;
@@ -528,9 +529,9 @@ __global__ void __launch_bounds__(kBlock) k_nee(const DevModel *__restrict__ Mp,
         gpis_nee_query qq = q[i];
         r.c = qq.coeff;
         V3 rd = v3(qq.ray_dir[0], qq.ray_dir[1], qq.ray_dir[2]), nn = v3(qq.normal[0], qq.normal[1], qq.normal[2]), p = v3(qq.p[0], qq.p[1], qq.p[2]);
-        if (pdf) pdf[i] = nee_pdf(*Mp, r, rd, nn, p, qq.t_segment, info_of(qq));
+        if (pdf) pdf[i] = generic::nee_pdf(*Mp, r, rd, nn, p, qq.t_segment, info_of(qq));
         if (grad3) {
-            V3 g = nee_grad(*Mp, r, rd, nn, p, info_of(qq));
+            V3 g = generic::nee_grad(*Mp, r, rd, nn, p, info_of(qq));
             grad3[3 * i] = g.x; grad3[3 * i + 1] = g.y; grad3[3 * i + 2] = g.z;
         }
     }
@@ -768,8 +769,8 @@ __global__ void __launch_bounds__(256) k_paths_keys(const DevModel *__restrict__
         const V3 d = v3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
         V3 u = p;
         if (M.iso3d) {
-            const Frame coord = frame_from_normal(normalized(cov_pos_w2l(M, d, 1.0f)));
-            u = to_local(coord, cov_pos_w2l(M, p, 1.0f));
+            const Frame coord = frame_from_normal(normalized(generic::cov_pos_w2l(M, d, 1.0f)));
+            u = to_local(coord, generic::cov_pos_w2l(M, p, 1.0f));
         }
         const float inv = 1.0f / cell_size;
         const int cx = (int)floorf(fminf(fmaxf(u.x * inv, -255.f), 255.f)) + 256;
@@ -1107,9 +1108,9 @@ extern "C" const char *gpis_abi_sizes(void)
     static char buf[512];
     snprintf(buf, sizeof buf,
              "gpis_params=%zu,gpis_mean=%zu,gpis_ray_in=%zu,gpis_seg_out=%zu,gpis_cond_coeff=%zu,gpis_query=%zu,"
-             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu,gpis_surface_s=%zu,gpis_ramp=%zu",
+             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu,gpis_surface_s=%zu,gpis_ramp=%zu,gpis_fs_state=%zu",
              sizeof(gpis_params), sizeof(gpis_mean), sizeof(gpis_ray_in), sizeof(gpis_seg_out), sizeof(gpis_cond_coeff),
-             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s), sizeof(gpis_surface_s), sizeof(gpis_ramp));
+             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s), sizeof(gpis_surface_s), sizeof(gpis_ramp), sizeof(gpis_fs_state));
     return buf;
 }
 
@@ -1129,6 +1130,7 @@ extern "C" void gpis_default_params(gpis_params *p)
     p->ls_min = 1.; p->ls_max = 500.; p->ls_start = 0.; p->ls_end = 1.;
     p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          // GPF.hpp:694-699
     p->matern_v = 0.5f; p->gabor_a_inv = 1.f; p->gabor_f_inv = 1.f; p->gabor_omega[0] = 1.f;   // GPF.hpp:1964, 2041, 2079
+    p->fs_sample_points = 32; p->fs_step_size = 0.;                                  // FunctionSpace...cpp:24-26
     gpis_ramp *ramps[4] = {&p->var, &p->mean_color, &p->mean_emission, &p->aniso_field};
     for (gpis_ramp *r : ramps) { r->min = 1.; r->max = 500.; r->start = 0.; r->end = 1.; r->min2 = 1.; r->max2 = 500.; r->start2 = 0.; r->end2 = 1.; }
     p->mean.type = GPIS_MEAN_SPHERICAL; p->mean.radius = 1.f;

@@ -60,7 +60,7 @@ GPIS_DEV Frame wave_frame(const DevModel &M, V3 dir)
 {
     Frame c{};
     if (M.iso3d)
-        c = frame_from_normal(normalized(cov_pos_w2l(M, dir, 1.0f)));
+        c = frame_from_normal(normalized(spec_3d::cov_pos_w2l(M, dir, 1.0f)));
     return c;
 }
 GPIS_DEV V3 wave_point(const WaveRay &w, double tq) { return to_f(ray_at(to_d(w.pos), to_d(w.dir), tq)); }
