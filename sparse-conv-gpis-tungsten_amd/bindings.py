@@ -262,6 +262,7 @@ class GpisLib:
         "gpis_sample_distance_batch", "gpis_transmittance_batch", "gpis_eval_value_batch",
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
         "gpis_xxhash32_batch", "gpis_pcg32_stream_batch", "gpis_mean_color_emission_batch", "gpis_mean_color_emission_host",
+        "gpis_fs_sample_distance_batch", "gpis_fs_transmittance_batch",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
@@ -398,6 +399,31 @@ class Medium:
         self.L.check(self.L.lib.gpis_transmittance_host(self.h, rays.shape[0], _ptr(rays), _ptr(vis)),
                      "gpis_transmittance_host")
         return vis
+
+    # ---- function-space comparison path: device-pointer entries, fed through torch buffers here
+    def _fs_call(self, fn_name, rays, states, want_out):
+        import torch
+        rays = np.ascontiguousarray(rays, dtype=RAY_IN)
+        states = np.ascontiguousarray(states, dtype=FS_STATE)
+        n = rays.shape[0]
+        dev = torch.device("cuda", self.device)
+        d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1)).to(dev)
+        d_st = torch.from_numpy(states.view(np.uint8).reshape(-1).copy()).to(dev)
+        d_out = torch.zeros(max(n, 1) * (SEG_OUT.itemsize if want_out else 1), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        rc = getattr(self.L.lib, fn_name)(self.h, n, ctypes.c_void_p(d_rays.data_ptr()), ctypes.c_void_p(d_st.data_ptr()),
+                                          ctypes.c_void_p(d_out.data_ptr()), None)
+        self.L.check(rc, fn_name)
+        torch.cuda.synchronize(dev)
+        st = d_st.cpu().numpy().view(FS_STATE).copy()
+        raw = d_out.cpu().numpy()
+        return (raw[:n * SEG_OUT.itemsize].view(SEG_OUT).copy() if want_out else raw[:n].copy()), st
+
+    def fs_sample_distance(self, rays, states):
+        return self._fs_call("gpis_fs_sample_distance_batch", rays, states, True)
+
+    def fs_transmittance(self, rays, states):
+        return self._fs_call("gpis_fs_transmittance_batch", rays, states, False)
 
     def mean_color_emission(self, points):
         """(color, emission) of the mean at double-precision points (n, 3)"""

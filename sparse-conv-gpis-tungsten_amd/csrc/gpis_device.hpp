@@ -78,6 +78,10 @@ struct DevModel {
     float matern_v, k_l;          // "v", "lengthScale"
     float gabor_a, gabor_f;       // 1 / a_inv, 1 / f_inv
     float gabor_omega[3];         // normalised
+    // function-space comparison path (gpis_fs.hpp): sample_points, step_size, the covariance's own aniso (GPF.hpp:1602-1605)
+    int32_t fs_n;
+    float fs_aniso[3];
+    double fs_step;
     // multi-resolution level tables (host libm: powf / logf), index level - kLevelMin
     float level_scale[kLevels];           // powf(2.5, level)
     int32_t level_addseed[kLevels];       // (int)floorf(logf(level_scale)/logf(2.5))

@@ -1,0 +1,750 @@
+// gpis_fs.hpp — the function-space comparison path on one wave per segment.
+//
+//   FunctionSpaceGaussianProcessMedium::intersectGP / sampleGradient   media/FunctionSpaceGaussianProcessMedium.cpp:58-345
+//   GPRealNodeValues::{makeIntersect, sampleGrad, applyMemory}          math/GaussianProcess.cpp:76-168
+//   GaussianProcess::{mean_and_cov, cov_sym, cov, sample_start_value, sample_cond, create_mvn_cond}, pseudo_inverse
+//                                                                       math/GaussianProcess.cpp:314-753
+//   MultivariateNormalDistribution, rand_truncated_normal               sampling/Gaussian.cpp:57-232
+//   Eigen::SelfAdjointEigenSolver / Eigen::LLT as the reference's Eigen implements them (vendored sources:
+//   Eigenvalues/{SelfAdjointEigenSolver,Tridiagonalization}.h, Householder/*.h, Jacobi/Jacobi.h, Cholesky/LLT.h)
+//
+// One segment = (64 + c)^2 doubles of dense linear algebra (c <= 66 conditioning entries): covariance build, a symmetric
+// eigen-decomposition for the pseudo-inverse, two matrix products, a Cholesky factorisation (or a second eigen-decomposition
+// when it fails — the rule for squared-exponential covariances on a fine grid), 64 normal variates.  All of it lives in the
+// 160 KB of LDS of one CU (146 KB used: one workgroup of one wave per CU) in fp64; lane = matrix row, inner sums run serially
+// in ascending index order inside each lane, so every value is produced by the same sequence of IEEE operations as in the
+// CPU restatement (exp / log / sin / cos excepted).  No MFMA: the products are 66 x 66 x 64 fp64 with a data-dependent
+// factorisation between them.
+#pragma once
+#include "gpis_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace gpis {
+
+constexpr int kFsN = GPIS_FS_MAX_POINTS, kFsC = GPIS_FS_MAX_CTX;
+constexpr int FS_NONE = 0, FS_FIRST = 1;
+
+struct FsLds {
+    double B1[kFsC * kFsC];      // s11 -> its eigenvectors -> its pseudo-inverse; later the normal transform T
+    double B2[kFsC * kFsC];      // scaled eigenvectors; later (pinv * s12)
+    double B3[kFsC * kFsN];      // s12
+    double B4[kFsN * kFsN];      // s22 -> conditional covariance
+    double w[kFsC], sub[kFsC], hco[kFsC], hv[kFsC], tmp[kFsC];
+    double mean[kFsC], z[kFsC], vals[kFsC], cv[kFsC], resid[kFsC], ts[kFsN];
+    double pts[kFsC][3], cpts[kFsC][3], dirs[3][3];
+    int der[kFsC], cder[kFsC];
+};
+static_assert(sizeof(FsLds) <= 160 * 1024, "the function-space workspace must fit the LDS of one CU");
+
+#define FS_SYNC() __syncthreads()
+
+GPIS_DEV double fs_dot(V3d a, V3d b) { double r = a.x * b.x; r += a.y * b.y; r += a.z * b.z; return r; }
+GPIS_DEV V3d fs_v3(const double *p) { return V3d{p[0], p[1], p[2]}; }
+
+// CovarianceFunction::operator()(Derivative, Derivative, ...), GPF.hpp:1145-1158, squared exponential in its GP form
+// (GPF.hpp:86-89, 1602-1605; GPF.cpp:770-772); the derivatives are the closed forms of what autodiff returns (GPF.cpp:490-504)
+GPIS_DEV double fs_cov(const DevModel &M, int da, int db, V3d a, V3d b, V3d dirA, V3d dirB)
+{
+    const V3d an{(double)M.fs_aniso[0], (double)M.fs_aniso[1], (double)M.fs_aniso[2]};
+    const V3d d{b.x - a.x, b.y - a.y, b.z - a.z};
+    const V3d ad{an.x * d.x, an.y * d.y, an.z * d.z};
+    const double absq = fs_dot(d, ad);
+    const float s2 = M.sigma_raw * M.sigma_raw, l2 = M.k_l * M.k_l;
+    const double c = (double)s2 * exp(-absq / (double)(2 * l2));
+    if (da == FS_NONE && db == FS_NONE)
+        return c;
+    if (da == FS_FIRST && db == FS_NONE)
+        return c * (fs_dot(ad, dirA) / (double)l2);
+    if (da == FS_NONE && db == FS_FIRST)
+        return c * (-fs_dot(ad, dirB) / (double)l2);
+    const V3d adB{an.x * dirB.x, an.y * dirB.y, an.z * dirB.z};
+    return c * (fs_dot(dirA, adB) / (double)l2) - c * (fs_dot(ad, dirA) / (double)l2) * (fs_dot(ad, dirB) / (double)l2);
+}
+// MeanFunction::operator()(Derivative, p, d), GPF.hpp:829-836
+GPIS_DEV double fs_mean(const DevModel &M, int deriv, V3d p, V3d dir)
+{
+    if (deriv == FS_NONE)
+        return mean_eval(M, 0, p);
+    return fs_dot(dir, mean_grad(M, 0, p));
+}
+GPIS_DEV double fs_wave_max(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// Eigen::SelfAdjointEigenSolver<MatrixXd>::compute on the n x n column-major matrix A (lower triangle read): on return the
+// columns of A are the eigenvectors and L.w the eigenvalues, ascending.  Every lane runs the scalar recurrences on the same
+// data; lane 0 stores them.
+GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
+{
+#define E(i, j) A[(j) * n + (i)]
+    if (n == 1) {
+        if (lane == 0) { L.w[0] = E(0, 0); E(0, 0) = 1.0; }
+        FS_SYNC();
+        return;
+    }
+    double scale = 0.0;
+    for (int i = lane; i < n; i += 64)
+        for (int j = 0; j <= i; ++j) { const double v = fabs(E(i, j)); if (v > scale) scale = v; }
+    scale = fs_wave_max(scale);
+    if (scale == 0.0) scale = 1.0;
+    for (int i = lane; i < n; i += 64)
+        for (int j = 0; j <= i; ++j) E(i, j) /= scale;
+    FS_SYNC();
+    for (int i = 0; i < n - 1; ++i) {                       // tridiagonalization_inplace, Tridiagonalization.h:352-383
+        const int rs = n - i - 1;
+        double tailSq = 0.0;
+        for (int k = i + 2; k < n; ++k) tailSq += E(k, i) * E(k, i);
+        const double c0 = E(i + 1, i);
+        double h, beta;
+        FS_SYNC();
+        if (tailSq <= 2.2250738585072014e-308) {            // makeHouseholder, Householder.h:70-99
+            h = 0.0; beta = c0;
+            for (int k = i + 2 + lane; k < n; k += 64) E(k, i) = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tailSq);
+            if (c0 >= 0.0) beta = -beta;
+            for (int k = i + 2 + lane; k < n; k += 64) E(k, i) = E(k, i) / (c0 - beta);
+            h = (beta - c0) / beta;
+        }
+        if (lane == 0) E(i + 1, i) = 1.0;
+        FS_SYNC();
+        for (int r = lane; r < rs; r += 64) {
+            double s = 0.0;
+            for (int c = 0; c < rs; ++c) {
+                const double a = r >= c ? E(i + 1 + r, i + 1 + c) : E(i + 1 + c, i + 1 + r);
+                s += a * (h * E(i + 1 + c, i));
+            }
+            L.hv[r] = s;
+        }
+        FS_SYNC();
+        double dotp = 0.0;
+        for (int r = 0; r < rs; ++r) dotp += L.hv[r] * E(i + 1 + r, i);
+        const double alpha = h * -0.5 * dotp;
+        FS_SYNC();
+        for (int r = lane; r < rs; r += 64) L.hv[r] += alpha * E(i + 1 + r, i);
+        FS_SYNC();
+        for (int r = lane; r < rs; r += 64) {
+            const double hr = L.hv[r], vr = E(i + 1 + r, i);
+            for (int c = 0; c <= r; ++c) {
+                const double uc = -E(i + 1 + c, i), wc = -L.hv[c];
+                E(i + 1 + r, i + 1 + c) += uc * hr + wc * vr;
+            }
+        }
+        FS_SYNC();
+        if (lane == 0) { E(i + 1, i) = beta; L.hco[i] = h; }
+        FS_SYNC();
+    }
+    for (int k = lane; k < n; k += 64) {
+        L.w[k] = E(k, k);
+        if (k < n - 1) L.sub[k] = E(k + 1, k);
+    }
+    FS_SYNC();
+    // Q = HouseholderSequence(mat, hCoeffs).setLength(n - 1).setShift(1), evaluated in place (HouseholderSequence.h:293-318)
+    for (int r = lane; r < n; r += 64) {
+        E(r, r) = 1.0;
+        for (int k = r + 1; k < n; ++k) E(r, k) = 0.0;
+    }
+    FS_SYNC();
+    for (int k = n - 2; k >= 0; --k) {
+        const int cs = n - k - 1, o = k + 1;
+        const double tau = L.hco[k];
+        if (cs == 1) {
+            if (lane == 0) E(o, o) *= 1.0 - tau;
+        } else if (tau != 0.0) {                            // applyHouseholderOnTheLeft, Householder.h:119-137
+            for (int c = lane; c < cs; c += 64) {
+                double s = 0.0;
+                for (int r = 1; r < cs; ++r) s += E(k + 1 + r, k) * E(o + r, o + c);
+                L.tmp[c] = s + E(o, o + c);
+            }
+            FS_SYNC();
+            for (int c = lane; c < cs; c += 64) E(o, o + c) -= tau * L.tmp[c];
+            for (int r = 1 + lane; r < cs; r += 64) {
+                const double te = tau * E(k + 1 + r, k);
+                for (int c = 0; c < cs; ++c) E(o + r, o + c) -= te * L.tmp[c];
+            }
+        }
+        FS_SYNC();
+        for (int r = k + 1 + lane; r < n; r += 64) E(r, k) = 0.0;
+        FS_SYNC();
+    }
+    {   // computeFromTridiagonal_impl (m_maxIterations = 30), SelfAdjointEigenSolver.h:504-579, tridiagonal_qr_step :841-900
+        int end = n - 1, start = 0, iter = 0;
+        const double considerAsZero = 2.2250738585072014e-308, precision_inv = 1.0 / 2.220446049250313e-16;
+        while (end > 0) {
+            for (int i = start + lane; i < end; i += 64) {
+                const double si = L.sub[i];
+                if (fabs(si) < considerAsZero) {
+                    L.sub[i] = 0.0;
+                } else {
+                    const double ss = precision_inv * si;
+                    if (ss * ss <= (fabs(L.w[i]) + fabs(L.w[i + 1]))) L.sub[i] = 0.0;
+                }
+            }
+            FS_SYNC();
+            while (end > 0 && L.sub[end - 1] == 0.0) end--;
+            if (end <= 0) break;
+            iter++;
+            if (iter > 30 * n) break;
+            start = end - 1;
+            while (start > 0 && L.sub[start - 1] != 0.0) start--;
+            const double td = (L.w[end - 1] - L.w[end]) * 0.5, e = L.sub[end - 1];
+            double mu = L.w[end];
+            if (td == 0.0) {
+                mu -= fabs(e);
+            } else if (e != 0.0) {
+                const double e2 = e * e;
+                // numext::hypot = positive_real_hypot(|td|, |e|), MathFunctionsImpl.h:216-232
+                const double ax = fabs(td), ay = fabs(e), p = ax > ay ? ax : ay, qp = (ay < ax ? ay : ax) / p;
+                const double hh = p * sqrt(1.0 + qp * qp);
+                if (e2 == 0.0) mu -= e / ((td + (td > 0.0 ? hh : -hh)) / e);
+                else mu -= e2 / (td + (td > 0.0 ? hh : -hh));
+            }
+            // the scalar recurrence runs in registers (w[k], sub[k], sub[k-1] are the previous iteration's results); w[k+1] and
+            // sub[k+1] are still untouched in LDS when iteration k reads them
+            double wk = L.w[start], sk = L.sub[start], skm1 = 0.0;
+            double x = wk - mu, z = sk;
+            FS_SYNC();
+            for (int k = start; k < end && z != 0.0; ++k) {
+                double gc, gs;                              // JacobiRotation::makeGivens(x, z), Jacobi.h:234-270
+                if (x == 0.0) { gc = 0.0; gs = z < 0.0 ? 1.0 : -1.0; }
+                else if (fabs(x) > fabs(z)) { const double t = z / x; double u = sqrt(1.0 + t * t); if (x < 0.0) u = -u; gc = 1.0 / u; gs = -t * gc; }
+                else { const double t = x / z; double u = sqrt(1.0 + t * t); if (z < 0.0) u = -u; gs = -1.0 / u; gc = -t * gs; }
+                const double wk1 = L.w[k + 1];
+                const double sdk = gs * wk + gc * sk;
+                const double dkp1 = gs * sk + gc * wk1;
+                const double nwk = gc * (gc * wk - gs * sk) - gs * (gc * sk - gs * wk1);
+                const double nwk1 = gs * sdk + gc * dkp1;
+                const double nsk = gc * sdk - gs * dkp1;
+                double nskm1 = skm1;
+                if (k > start) nskm1 = gc * skm1 - gs * z;
+                x = nsk;
+                double nsk1 = 0.0;
+                if (k < end - 1) { const double sk1 = L.sub[k + 1]; z = -gs * sk1; nsk1 = gc * sk1; }
+                if (lane == 0) {
+                    L.w[k] = nwk; L.w[k + 1] = nwk1; L.sub[k] = nsk;
+                    if (k > start) L.sub[k - 1] = nskm1;
+                    if (k < end - 1) L.sub[k + 1] = nsk1;
+                }
+                for (int i = lane; i < n; i += 64) {        // q.applyOnTheRight(k, k + 1, rot)
+                    const double xi = E(i, k), yi = E(i, k + 1);
+                    E(i, k) = gc * xi - gs * yi;
+                    E(i, k + 1) = gs * xi + gc * yi;
+                }
+                wk = nwk1; sk = nsk1; skm1 = nsk;
+            }
+            FS_SYNC();
+        }
+        if (iter <= 30 * n) {
+            for (int i = 0; i < n - 1; ++i) {
+                int k = 0;
+                for (int j = 1; j < n - i; ++j) if (L.w[i + j] < L.w[i + k]) k = j;
+                FS_SYNC();
+                if (k > 0) {
+                    if (lane == 0) { const double t = L.w[i]; L.w[i] = L.w[k + i]; L.w[k + i] = t; }
+                    for (int r = lane; r < n; r += 64) { const double q = E(r, i); E(r, i) = E(r, k + i); E(r, k + i) = q; }
+                }
+                FS_SYNC();
+            }
+        }
+    }
+    for (int k = lane; k < n; k += 64) L.w[k] *= scale;
+    FS_SYNC();
+#undef E
+}
+
+// pseudo_inverse, GaussianProcess.cpp:645-662: A (n x n in B1) is replaced by its pseudo-inverse; B2 is scratch
+GPIS_DEV void fs_pinv(FsLds &L, int n, int lane)
+{
+    double *A = L.B1, *U = L.B2;
+    fs_eigh(L, n, A, lane);
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) { const double v = fabs(L.w[i]); if (v > mx) mx = v; }
+    const double eps = 1e6 * 2.220446049250313e-16 * mx;
+    for (int i = lane; i < n; i += 64)
+        for (int k = 0; k < n; ++k) {
+            const double wk = L.w[k];
+            const double sp = fabs(wk) <= eps ? 0.0 : 1.0 / wk;
+            U[k * n + i] = A[k * n + i] * sqrt(sp);
+        }
+    FS_SYNC();
+    for (int i = lane; i < n; i += 64)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += U[k * n + i] * U[k * n + j];
+            A[j * n + i] = s;
+        }
+    FS_SYNC();
+}
+
+// normTransform of MultivariateNormalDistribution, Gaussian.cpp:121-167: S (n x n in B4) -> T (in B1)
+GPIS_DEV void fs_norm_transform(FsLds &L, int n, int lane)
+{
+    const double *S = L.B4;
+    double *T = L.B1;
+    for (int i = lane; i < n; i += 64)
+        for (int j = 0; j < n; ++j) T[j * n + i] = S[j * n + i];
+    FS_SYNC();
+    bool ok = true;
+#define LL(i, j) T[(j) * n + (i)]
+    for (int k = 0; k < n; ++k) {                           // LLT (Cholesky/LLT.h): a pivot x <= 0 is the failure
+        double x = LL(k, k);
+        for (int j = 0; j < k; ++j) x -= LL(k, j) * LL(k, j);
+        if (x <= 0.0) { ok = false; break; }
+        x = sqrt(x);
+        FS_SYNC();
+        if (lane == 0) LL(k, k) = x;
+        for (int i = k + 1 + lane; i < n; i += 64) {
+            double s = LL(i, k);
+            for (int j = 0; j < k; ++j) s -= LL(i, j) * LL(k, j);
+            LL(i, k) = s / x;
+        }
+        FS_SYNC();
+    }
+    FS_SYNC();
+    if (ok) {
+        for (int i = lane; i < n; i += 64)
+            for (int j = i + 1; j < n; ++j) LL(i, j) = 0.0;
+        FS_SYNC();
+        return;
+    }
+#undef LL
+    for (int i = lane; i < n; i += 64)
+        for (int j = 0; j < n; ++j) T[j * n + i] = S[j * n + i];
+    FS_SYNC();
+    fs_eigh(L, n, T, lane);
+    for (int i = lane; i < n; i += 64)
+        for (int k = 0; k < n; ++k) {
+            const double wk = L.w[k];
+            T[k * n + i] *= sqrt(wk > 0.0 ? wk : 0.0);
+        }
+    FS_SYNC();
+}
+
+GPIS_DEV double fs_next1d(Pcg32 &s) { return (double)normalized_uint(s.next_i()); }
+// rand_truncated_normal, Gaussian.cpp:57-85 (the rejection loop is capped: a wave must terminate)
+GPIS_DEV double fs_rand_truncated_normal(double mean, double sigma, double a, Pcg32 &s)
+{
+    double z1, z2;
+    if (fabs(a - mean) < 0.000001) {
+        rand_normal_2(s, z1, z2);
+        return fabs(mean + sigma * z1);
+    }
+    if (a < mean) {
+        for (int it = 0; it < (1 << 20); ++it) {
+            rand_normal_2(s, z1, z2);
+            const double x = mean + sigma * z1;
+            if (x >= a) return x;
+        }
+        return a;
+    }
+    const double a_bar = (a - mean) / sigma;
+    double x_bar = 0.0;
+    for (int i = 0; i < 1000; i++) {
+        const double u = fs_next1d(s);
+        x_bar = sqrt(a_bar * a_bar - 2 * log(1 - u));
+        const double v = fs_next1d(s);
+        if (v < x_bar / a_bar) break;
+    }
+    return sigma * x_bar + mean;
+}
+
+// GaussianProcess::sample / sample_cond -> create_mvn_cond -> MultivariateNormalDistribution::sample (one sample), with
+// L.pts / L.der (+ L.dirs when has_dirs) the n target entries and L.cpts / L.cder / L.cv the nc conditioning entries.
+// Result in L.vals[0 .. n).  GaussianProcess.cpp:605-632, 664-753; Gaussian.cpp:179-232.
+GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, int n, int nc, V3d deriv_dir, bool has_dirs, Pcg32 &s, int lane)
+{
+    double *S = L.B4, *s11 = L.B1, *s12 = L.B3, *sol = L.B2;
+    auto dir_of = [&](int i) { return has_dirs ? fs_v3(L.dirs[i]) : deriv_dir; };
+    for (int i = lane; i < n; i += 64) {
+        L.mean[i] = fs_mean(M, L.der[i], fs_v3(L.pts[i]), dir_of(i));
+        for (int j = 0; j <= i; ++j) {
+            const double c = fs_cov(M, L.der[i], L.der[j], fs_v3(L.pts[i]), fs_v3(L.pts[j]), dir_of(i), dir_of(j));
+            S[j * n + i] = c;
+            S[i * n + j] = c;
+        }
+    }
+    FS_SYNC();
+    if (nc > 0) {
+        for (int i = lane; i < nc; i += 64)
+            for (int j = 0; j <= i; ++j) {
+                const double c = fs_cov(M, L.cder[i], L.cder[j], fs_v3(L.cpts[i]), fs_v3(L.cpts[j]), deriv_dir, deriv_dir);
+                s11[j * nc + i] = c;
+                s11[i * nc + j] = c;
+            }
+        for (int j = lane; j < n; j += 64)
+            for (int i = 0; i < nc; ++i)
+                s12[j * nc + i] = fs_cov(M, L.cder[i], L.der[j], fs_v3(L.cpts[i]), fs_v3(L.pts[j]), deriv_dir, dir_of(j));
+        FS_SYNC();
+        fs_pinv(L, nc, lane);
+        for (int i = lane; i < nc; i += 64)
+            for (int j = 0; j < n; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < nc; ++k) acc += s11[k * nc + i] * s12[j * nc + k];
+                sol[j * nc + i] = acc;
+            }
+        for (int k = lane; k < nc; k += 64) L.resid[k] = L.cv[k] - fs_mean(M, L.cder[k], fs_v3(L.cpts[k]), deriv_dir);
+        FS_SYNC();
+        for (int i = lane; i < n; i += 64) {
+            double acc = 0.0;
+            for (int k = 0; k < nc; ++k) acc += sol[i * nc + k] * L.resid[k];
+            L.mean[i] += acc;
+            for (int j = 0; j < n; ++j) {
+                double a2 = 0.0;
+                for (int k = 0; k < nc; ++k) a2 += sol[i * nc + k] * s12[j * nc + k];
+                S[j * n + i] -= a2;
+            }
+        }
+        FS_SYNC();
+    }
+    fs_norm_transform(L, n, lane);
+    // the variates: every lane advances its copy of the sampler identically
+    for (int i = 0; i < n / 2; i++) {
+        double a, b;
+        rand_normal_2(s, a, b);
+        if (lane == 0) { L.z[i * 2] = a; L.z[i * 2 + 1] = b; }
+    }
+    if (n % 2) {
+        double a, b;
+        rand_normal_2(s, a, b);
+        if (lane == 0) L.z[n - 1] = a;
+    }
+    FS_SYNC();
+    const double *T = L.B1;
+    for (int i = lane; i < n; i += 64) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += T[j * n + i] * L.z[j];
+        L.vals[i] = L.mean[i] + acc;
+    }
+    FS_SYNC();
+}
+
+// TangentFrameD(n), TangentFrame.hpp:28-37
+GPIS_DEV void fs_frame(V3d n, V3d &tangent, V3d &bitangent)
+{
+    const double sign = n.z < 0 ? -1. : 1.;
+    const double a = -1.0 / (sign + n.z);
+    const double b = n.x * n.y * a;
+    tangent = V3d{1.0 + sign * n.x * n.x * a, sign * b, -sign * n.x};
+    bitangent = V3d{b, sign + n.y * n.y * a, -n.y};
+}
+
+// FunctionSpaceGaussianProcessMedium::intersectGP, FunctionSpace...cpp:58-282 (skip_space = 0).  The state record lives in
+// global memory and is rewritten on return; wave-uniform result.
+GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, Pcg32 &s, V3 pos, V3 dir, float ray_near, float ray_far, bool first_scatter,
+                              bool firstIsectAlongRay, gpis_fs_state *st, int &last_gp_id, double &t_out, int lane)
+{
+    const int n = M.fs_n;
+    const double tOffset = fs_next1d(s);
+    const V3d ro = to_d(pos);
+    V3d rd = to_d(dir);
+    { const double inv = 1.0 / length_d(rd); rd.x *= inv; rd.y *= inv; rd.z *= inv; }
+    const double nearT = (double)ray_near, farT = (double)ray_far;
+    double maxRayDist = farT - nearT;
+    double step = maxRayDist / n;
+    if (M.fs_step > 0 && M.fs_step < step)
+        step = M.fs_step;
+    maxRayDist = step * n;
+    const double maxT = nearT + maxRayDist;
+    for (int i = lane; i < n; i += 64) {
+        double r = (i - tOffset) / (n - 1);
+        r = r < 0. ? 0. : (r > 1. ? 1. : r);
+        double rt = lerp_d((double)ray_near + step * 0.1, (double)ray_near + maxRayDist, r);
+        if (i == 0) rt = nearT + step * 0.1;
+        else if (i == n - 1) rt = nearT + maxRayDist;
+        L.ts[i] = rt;
+        const V3d p = ray_at(ro, rd, rt);
+        L.pts[i][0] = p.x; L.pts[i][1] = p.y; L.pts[i][2] = p.z;
+        L.der[i] = FS_NONE;
+    }
+    const bool conditioned = !first_scatter && st->has_context;
+    if (conditioned && st->n_points == 0)
+        return false;
+    int nc = 0;
+    if (!conditioned) {
+        // sample_start_value: drawn, then unused — numCondPts is 0 in the call (FunctionSpace...cpp:139-148)
+        const V3d rp = to_d(pos + dir * ray_near);
+        const V3d zero{0., 0., 0.};
+        const double mu = fs_mean(M, FS_NONE, rp, zero), sigma = sqrt(fs_cov(M, FS_NONE, FS_NONE, rp, rp, zero, zero));
+        (void)fs_rand_truncated_normal(mu, sigma, 0, s);
+    } else {
+        const int np = st->n_points, nv = st->n_values;
+        const V3d last = fs_v3(st->points[np - 1]);
+        const double sg_rd = fs_dot(fs_v3(st->sampled_grad), rd);
+        const double v_last = st->is_intersect ? st->values[nv - 2] : st->values[nv - 1];      // applyMemory, GaussianProcess.cpp:134-168
+        if (M.ctx == GPIS_CTX_RENEWAL || M.ctx == GPIS_CTX_RENEWAL_PLUS) {
+            nc = M.ctx == GPIS_CTX_RENEWAL ? 1 : 2;
+            if (lane < nc) {
+                L.cpts[lane][0] = last.x; L.cpts[lane][1] = last.y; L.cpts[lane][2] = last.z;
+                L.cder[lane] = lane == 0 ? FS_NONE : FS_FIRST;
+                L.cv[lane] = lane == 0 ? v_last : sg_rd;
+            }
+        } else if (M.ctx == GPIS_CTX_GLOBAL) {
+            nc = np;
+            for (int i = lane; i < nc; i += 64) {
+                L.cpts[i][0] = st->points[i][0]; L.cpts[i][1] = st->points[i][1]; L.cpts[i][2] = st->points[i][2];
+                L.cder[i] = st->derivs[i];
+                L.cv[i] = st->values[i];
+            }
+            FS_SYNC();
+            if (!st->is_intersect) {
+                if (lane == 0) { L.cpts[nc][0] = last.x; L.cpts[nc][1] = last.y; L.cpts[nc][2] = last.z; L.cder[nc] = FS_FIRST; }
+                nc++;
+            }
+            FS_SYNC();
+            if (lane == 0) L.cv[nc - 1] = sg_rd;
+        }
+    }
+    FS_SYNC();
+    fs_sample_cond(M, L, n, nc, rd, false, s, lane);
+    // the march over the sampled values (every lane walks the same array)
+    double prevV = L.vals[0];
+    int sign0 = prevV < 0 ? -1 : 1;
+    double prevT = L.ts[0];
+    for (int p = 1; p < n; p++) {
+        const double currV = L.vals[p], currT = L.ts[p];
+        const int signc = currV < 0 ? -1 : 1;
+        if (!first_scatter && firstIsectAlongRay && p == 1) {
+            sign0 = signc;
+        } else if (signc != sign0) {
+            const double offsetT = prevV / (prevV - currV);
+            const double t = lerp_d(prevT, currT, offsetT);
+            const V3d ip = ray_at(ro, rd, t);
+            FS_SYNC();
+            for (int i = lane; i < p + 2; i += 64) {
+                double v = L.vals[i];
+                V3d q = fs_v3(L.pts[i]);
+                int dv = FS_NONE;
+                if (i == p) { v = lerp_d(prevV, currV, offsetT); q = ip; }                  // makeIntersect, GaussianProcess.cpp:76-87
+                if (i == p + 1) { v = (prevV - currV) / (prevT - currT); q = ip; dv = FS_FIRST; }
+                st->points[i][0] = q.x; st->points[i][1] = q.y; st->points[i][2] = q.z;
+                st->derivs[i] = dv; st->values[i] = v;
+            }
+            if (lane == 0) { st->has_context = 1; st->is_intersect = 1; st->n_points = p + 2; st->n_values = p + 2; }
+            last_gp_id = 0;
+            if (M.surf_vol_phase_separate)
+                last_gp_id = 1.f < M.surf_vol_phase_amp_thresh ? 0 : 1;
+            t_out = t;
+            __threadfence_block();
+            FS_SYNC();
+            return true;
+        }
+        prevV = currV;
+        prevT = currT;
+    }
+    FS_SYNC();
+    for (int i = lane; i < n; i += 64) {
+        st->points[i][0] = L.pts[i][0]; st->points[i][1] = L.pts[i][1]; st->points[i][2] = L.pts[i][2];
+        st->derivs[i] = FS_NONE; st->values[i] = L.vals[i];
+    }
+    if (lane == 0) { st->has_context = 1; st->is_intersect = 0; st->n_points = n; st->n_values = n; }
+    last_gp_id = 0;
+    t_out = maxT;
+    __threadfence_block();
+    FS_SYNC();
+    return false;
+}
+
+// sampleGradient (ConditionedGaussian) -> GPRealNodeValues::sampleGrad, FunctionSpace...cpp:284-305, GaussianProcess.cpp:89-132
+GPIS_DEV bool fs_sample_gradient(const DevModel &M, FsLds &L, Pcg32 &s, V3d rd, V3d ip, gpis_fs_state *st, V3d &grad, int lane)
+{
+    if (!st->has_context || st->n_points == 0)
+        return false;
+    V3d tangent, bitangent;
+    fs_frame(rd, tangent, bitangent);
+    const int nc = st->n_values;
+    const bool isect = st->is_intersect != 0;
+    const double slope = st->values[nc - 1];
+    FS_SYNC();
+    for (int i = lane; i < nc; i += 64) {
+        L.cpts[i][0] = st->points[i][0]; L.cpts[i][1] = st->points[i][1]; L.cpts[i][2] = st->points[i][2];
+        L.cder[i] = st->derivs[i];
+        L.cv[i] = st->values[i];
+    }
+    if (lane < 3) {
+        L.pts[lane][0] = ip.x; L.pts[lane][1] = ip.y; L.pts[lane][2] = ip.z;
+        L.der[lane] = FS_FIRST;
+        const V3d d = lane == 0 ? tangent : (lane == 1 ? bitangent : rd);
+        L.dirs[lane][0] = d.x; L.dirs[lane][1] = d.y; L.dirs[lane][2] = d.z;
+    }
+    FS_SYNC();
+    fs_sample_cond(M, L, isect ? 2 : 3, nc, rd, true, s, lane);
+    const double g0 = L.vals[0], g1 = L.vals[1], g2 = isect ? slope : L.vals[2];
+    grad.x = (tangent.x * g0 + bitangent.x * g1) + rd.x * g2;
+    grad.y = (tangent.y * g0 + bitangent.y * g1) + rd.y * g2;
+    grad.z = (tangent.z * g0 + bitangent.z * g1) + rd.z * g2;
+    FS_SYNC();
+    if (lane == 0) { st->sampled_grad[0] = grad.x; st->sampled_grad[1] = grad.y; st->sampled_grad[2] = grad.z; }
+    __threadfence_block();
+    FS_SYNC();
+    return true;
+}
+
+struct FsState { bool first_scatter; int last_gp_id; V3d last_aniso; };
+
+// GaussianProcessMedium::transmittance over the function-space intersectGP, GPM.cpp:343-393 -> exited (false = blocked or failed)
+GPIS_DEV bool fs_transmittance_one(const DevModel &M, FsLds &L, Pcg32 &s, const gpis_ray_in *ray, gpis_fs_state *st, FsState &state, int lane)
+{
+    const V3 pos = v3(ray->pos[0], ray->pos[1], ray->pos[2]), dir = v3(ray->dir[0], ray->dir[1], ray->dir[2]);
+    double startT = (double)ray->near_t;
+    float farT = ray->far_t;
+    if (!__builtin_isfinite(farT)) farT = (float)(startT + 2000);
+    const float maxT = farT;
+    double t = (double)maxT;
+    const V3d ro = to_d(pos);
+    V3d rd = to_d(dir);
+    { const double inv = 1.0 / length_d(rd); rd.x *= inv; rd.y *= inv; rd.z *= inv; }
+    bool exited, first = true;
+    do {
+        exited = !fs_intersect_gp(M, L, s, pos, dir, (float)startT, farT, state.first_scatter, first, st, state.last_gp_id, t, lane);
+        first = false;
+        if (t < (double)maxT) {
+            V3d grad;
+            if (!fs_sample_gradient(M, L, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane))
+                return false;
+            state.last_aniso = grad;
+            state.first_scatter = false;
+            if (!__builtin_isfinite((grad.x + grad.y + grad.z) / 3.0))
+                return false;
+        }
+        startT = t;
+    } while (t < (double)maxT && exited);
+    return exited;
+}
+
+template <bool WANT_SAMPLE>
+__global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp, size_t n_rays, const gpis_ray_in *__restrict__ rays,
+                                                 gpis_fs_state *__restrict__ states, gpis_seg_out *__restrict__ outs, uint8_t *__restrict__ visible)
+{
+    __shared__ FsLds L;
+    const DevModel &M = *Mp;
+    const int lane = (int)threadIdx.x;
+    for (size_t idx = blockIdx.x; idx < n_rays; idx += gridDim.x) {
+        const gpis_ray_in *ray = rays + idx;
+        gpis_fs_state *st = states + idx;
+        Pcg32 s;
+        s.state = st->sampler_state;
+        FsState state;
+        state.first_scatter = ray->first_scatter != 0;
+        state.last_gp_id = ray->last_gp_id;
+        state.last_aniso = V3d{ray->last_aniso[0], ray->last_aniso[1], ray->last_aniso[2]};
+        FS_SYNC();
+        if (!WANT_SAMPLE) {
+            const bool vis = fs_transmittance_one(M, L, s, ray, st, state, lane);
+            if (lane == 0) { visible[idx] = vis ? 1 : 0; st->sampler_state = s.state; }
+            continue;
+        }
+        // GaussianProcessMedium::sampleDistance, GPM.cpp:221-341
+        gpis_seg_out o{};
+        const V3 pos = v3(ray->pos[0], ray->pos[1], ray->pos[2]), dir = v3(ray->dir[0], ray->dir[1], ray->dir[2]);
+        double startT = (double)ray->near_t;
+        float farT = ray->far_t;
+        if (!__builtin_isfinite(farT)) farT = (float)(startT + 2000);
+        const float maxT = farT;
+        o.gp_id = state.last_gp_id;
+        o.last_val = ray->last_val;
+        V3d aniso = state.last_aniso;
+        bool finished = false;
+        if (ray->bounce >= M.max_bounces) {
+            o.ok = 0;
+            finished = true;
+        } else if (maxT == 0.f) {
+            o.sample_t = maxT;
+            o.weight[0] = o.weight[1] = o.weight[2] = 1.f;
+            o.exited = 1;
+            const V3 pp = pos + dir * o.sample_t;
+            o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
+            o.scheme = GPIS_UNI;
+            o.ok = 1;
+            finished = true;
+        } else if (M.absorption_only) {
+            if (maxT == __builtin_huge_valf()) {
+                o.ok = 0;
+                finished = true;
+            } else {
+                o.sample_t = maxT;
+                const bool vis = fs_transmittance_one(M, L, s, ray, st, state, lane);
+                o.weight[0] = o.weight[1] = o.weight[2] = vis ? 1.f : 0.f;
+                o.exited = 1;
+                o.scheme = GPIS_UNI;
+                aniso = state.last_aniso;
+            }
+        } else {
+            double t = (double)maxT;
+            const V3d ro = to_d(pos);
+            V3d rd = to_d(dir);
+            { const double inv = 1.0 / length_d(rd); rd.x *= inv; rd.y *= inv; rd.z *= inv; }
+            bool exited, first = true;
+            do {
+                exited = !fs_intersect_gp(M, L, s, pos, dir, (float)startT, farT, state.first_scatter, first, st, state.last_gp_id, t, lane);
+                first = false;
+                if (t < (double)maxT) {
+                    V3d grad;
+                    if (!fs_sample_gradient(M, L, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane)) {
+                        o.t = t; o.exited = exited; o.ok = 0; o.gp_id = state.last_gp_id;
+                        finished = true;
+                        break;
+                    }
+                    aniso = grad;
+                    state.last_aniso = aniso;
+                    state.first_scatter = false;
+                    if (!__builtin_isfinite((aniso.x + aniso.y + aniso.z) / 3.0)) {
+                        aniso = V3d{1., 0., 0.};
+                        o.t = t; o.exited = exited; o.ok = 0; o.gp_id = state.last_gp_id;
+                        finished = true;
+                        break;
+                    }
+                }
+                startT = t;
+            } while (t < (double)maxT && exited);
+            if (!finished) {
+                o.t = t;
+                o.exited = exited;
+                if (!exited) {
+                    double d = aniso.x * (double)dir.x; d += aniso.y * (double)dir.y; d += aniso.z * (double)dir.z;
+                    double l2 = 0.; l2 += aniso.x * aniso.x; l2 += aniso.y * aniso.y; l2 += aniso.z * aniso.z;
+                    if (d > 0) {
+                        o.gp_id = state.last_gp_id; o.ok = 0;
+                        finished = true;
+                    } else if (l2 < (double)0.0000001f) {
+                        aniso = V3d{1., 0., 0.};
+                        o.gp_id = state.last_gp_id; o.ok = 0;
+                        finished = true;
+                    } else {
+                        const float col = M.color.enabled ? (float)ramp_eval(M.color, ray_at(ro, rd, t)) : 1.f;
+                        o.weight[0] = o.weight[1] = o.weight[2] = col;
+                        o.continued_weight[0] = o.continued_weight[1] = o.continued_weight[2] = col;
+                    }
+                } else {
+                    V3d grad = aniso;
+                    (void)fs_sample_gradient(M, L, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane);   // GPM.cpp:319
+                    aniso = grad;
+                    o.weight[0] = o.weight[1] = o.weight[2] = 1.f;
+                    o.continued_weight[0] = o.continued_weight[1] = o.continued_weight[2] = 1.f;
+                }
+                if (!finished) {
+                    const float ft = (float)t;
+                    o.sample_t = ft < maxT ? ft : maxT;
+                    o.continued_t = (float)t;
+                    for (int c = 0; c < 3; ++c) {
+                        o.weight[c] *= M.sigma_s_over_t[c];
+                        o.continued_weight[c] *= M.sigma_s_over_t[c];
+                    }
+                    o.scheme = GPIS_UNI;
+                }
+            }
+        }
+        if (!finished) {
+            const V3 pp = pos + dir * o.sample_t;
+            o.p[0] = pp.x; o.p[1] = pp.y; o.p[2] = pp.z;
+            o.gp_id = state.last_gp_id;
+            o.ok = 1;
+        }
+        o.aniso[0] = aniso.x; o.aniso[1] = aniso.y; o.aniso[2] = aniso.z;
+        if (lane == 0) { outs[idx] = o; st->sampler_state = s.state; }
+    }
+}
+
+}   // namespace gpis

@@ -26,6 +26,7 @@
 #include "gpis_guide.hpp"
 #include "gpis_guide_range.hpp"
 #include "gpis_wave.hpp"
+#include "gpis_fs.hpp"
 
 #pragma clang fp contract(off)
 
@@ -304,6 +305,9 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
     M.kernel_type = P.kernel_type;
     M.matern_v = P.matern_v;
     M.k_l = P.length_scale;
+    M.fs_n = P.fs_sample_points;
+    M.fs_step = P.fs_step_size;
+    for (int i = 0; i < 3; ++i) M.fs_aniso[i] = P.aniso[i];
     M.gabor_a = (float)(1.0 / P.gabor_a_inv);
     M.gabor_f = (float)(1.0 / P.gabor_f_inv);
     {
@@ -1668,6 +1672,39 @@ extern "C" int gpis_mean_color_emission_batch(gpis_medium *m, size_t n, const do
     HIP_TRY(hipSetDevice(m->device));
     k_mean_color_emission<<<grid_of(n, 256), 256, 0, (hipStream_t)stream>>>(m->d_model, n, p3, color3, emission3);
     return launch_check("k_mean_color_emission");
+}
+// function-space comparison path: gpis_fs.hpp
+static int fs_check(gpis_medium *m)
+{
+    const DevModel &H = m->host_model;
+    if (H.fs_n < 2 || H.fs_n > GPIS_FS_MAX_POINTS || !(H.fs_step >= 0) || H.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL || H.nonstationary ||
+        H.use_aniso_mtx || H.has_mean_additional)
+        return set_err(GPIS_ERR_INVALID_ARG, "function-space path: squared-exponential covariance, analytic mean, 2..64 sample points");
+    return GPIS_OK;
+}
+template <bool WANT_SAMPLE>
+static int fs_launch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, uint8_t *visible, hipStream_t s)
+{
+    HIP_TRY(hipSetDevice(m->device));
+    // the workspace takes the LDS of a whole CU: one wave per CU is resident, a few per CU are queued
+    const size_t cap = (size_t)(m->n_cus > 0 ? m->n_cus : 256) * 4;
+    const unsigned grid = (unsigned)(n < cap ? n : cap);
+    k_fs_march<WANT_SAMPLE><<<grid, 64, 0, s>>>(m->d_model, n, rays, states, out, visible);
+    return launch_check("k_fs_march");
+}
+extern "C" int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && states && out)));
+    if (int st = fs_check(m)) return st;
+    if (n == 0) return GPIS_OK;
+    return fs_launch<true>(m, n, rays, states, out, nullptr, (hipStream_t)stream);
+}
+extern "C" int gpis_fs_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible, void *stream)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && states && visible)));
+    if (int st = fs_check(m)) return st;
+    if (n == 0) return GPIS_OK;
+    return fs_launch<false>(m, n, rays, states, nullptr, visible, (hipStream_t)stream);
 }
 extern "C" int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3)
 {
