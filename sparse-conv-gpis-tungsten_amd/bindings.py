@@ -363,6 +363,7 @@ class Medium:
     def __init__(self, params, device=0, lib=None):
         self.L = lib or load_library()
         self.params = as_params(params)
+        self.device = int(device)
         h = ctypes.c_void_p()
         st = self.L.lib.gpis_create(_ptr(self.params), int(device), ctypes.byref(h))
         self.L.check(st, "gpis_create")
