@@ -236,6 +236,11 @@ def params_for_config(name):
         p["multi_resolution_grid"] = 1
         p["ls_ramp_type"] = 0
         p["ls_min"], p["ls_max"], p["ls_start"], p["ls_end"] = 0.5, 2.0, -1.0, 1.0
+    elif name == "C4":    # FunctionSpaceGaussianProcessMedium comparison path: 64 sample points, global memory
+        p["correlation_context"] = CTX.GLOBAL
+        p["single_realization"] = 0
+        p["fs_sample_points"] = 64
+        p["fs_step_size"] = 0.0
     else:
         raise ValueError("unknown config %r" % name)
     return p
