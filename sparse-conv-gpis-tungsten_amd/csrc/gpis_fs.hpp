@@ -113,6 +113,7 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
         FS_SYNC();
         for (int r = lane; r < rs; r += 64) {
             double s = 0.0;
+            #pragma unroll 8
             for (int c = 0; c < rs; ++c) {
                 const double a = r >= c ? E(i + 1 + r, i + 1 + c) : E(i + 1 + c, i + 1 + r);
                 s += a * (h * E(i + 1 + c, i));
@@ -128,6 +129,7 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
         FS_SYNC();
         for (int r = lane; r < rs; r += 64) {
             const double hr = L.hv[r], vr = E(i + 1 + r, i);
+            #pragma unroll 8
             for (int c = 0; c <= r; ++c) {
                 const double uc = -E(i + 1 + c, i), wc = -L.hv[c];
                 E(i + 1 + r, i + 1 + c) += uc * hr + wc * vr;
@@ -156,6 +158,7 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
         } else if (tau != 0.0) {                            // applyHouseholderOnTheLeft, Householder.h:119-137
             for (int c = lane; c < cs; c += 64) {
                 double s = 0.0;
+                #pragma unroll 8
                 for (int r = 1; r < cs; ++r) s += E(k + 1 + r, k) * E(o + r, o + c);
                 L.tmp[c] = s + E(o, o + c);
             }
@@ -163,6 +166,7 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
             for (int c = lane; c < cs; c += 64) E(o, o + c) -= tau * L.tmp[c];
             for (int r = 1 + lane; r < cs; r += 64) {
                 const double te = tau * E(k + 1 + r, k);
+                #pragma unroll 8
                 for (int c = 0; c < cs; ++c) E(o + r, o + c) -= te * L.tmp[c];
             }
         }
@@ -202,17 +206,29 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
                 if (e2 == 0.0) mu -= e / ((td + (td > 0.0 ? hh : -hh)) / e);
                 else mu -= e2 / (td + (td > 0.0 ? hh : -hh));
             }
-            // the scalar recurrence runs in registers (w[k], sub[k], sub[k-1] are the previous iteration's results); w[k+1] and
-            // sub[k+1] are still untouched in LDS when iteration k reads them
+            // The sweep is one dependent chain (bulge chasing): what sits on it decides the time of the whole path.  The scalar
+            // recurrence runs in registers (w[k], sub[k], sub[k-1] are the previous rotation's results; w[k+1], sub[k+1] are still
+            // untouched in LDS and are fetched ONE ROTATION AHEAD), and each lane carries the element of its Q row that the next
+            // rotation needs (column k+1 after rotation k) instead of writing it and reading it back; column k+2 is fetched ahead
+            // as well.  The chain is then the two divisions and the square root of makeGivens, not LDS round trips.
             double wk = L.w[start], sk = L.sub[start], skm1 = 0.0;
             double x = wk - mu, z = sk;
+            const int ia = lane, ib = lane + 64;
+            const bool ha = ia < n, hb = ib < n;
+            double qa = ha ? E(ia, start) : 0.0, qb = hb ? E(ib, start) : 0.0;                 // column k of the lane's rows
+            double na = ha ? E(ia, start + 1) : 0.0, nb = hb ? E(ib, start + 1) : 0.0;         // column k + 1
+            double pw = L.w[start + 1], ps = start < end - 1 ? L.sub[start + 1] : 0.0;
             FS_SYNC();
-            for (int k = start; k < end && z != 0.0; ++k) {
+            int k = start;
+            for (; k < end && z != 0.0; ++k) {
+                const bool more = k + 2 <= end;
+                const double fa = (more && ha) ? E(ia, k + 2) : 0.0, fb = (more && hb) ? E(ib, k + 2) : 0.0;
+                const double fw = more ? L.w[k + 2] : 0.0, fsub = (k + 2 <= end - 1) ? L.sub[k + 2] : 0.0;
                 double gc, gs;                              // JacobiRotation::makeGivens(x, z), Jacobi.h:234-270
                 if (x == 0.0) { gc = 0.0; gs = z < 0.0 ? 1.0 : -1.0; }
                 else if (fabs(x) > fabs(z)) { const double t = z / x; double u = sqrt(1.0 + t * t); if (x < 0.0) u = -u; gc = 1.0 / u; gs = -t * gc; }
                 else { const double t = x / z; double u = sqrt(1.0 + t * t); if (z < 0.0) u = -u; gs = -1.0 / u; gc = -t * gs; }
-                const double wk1 = L.w[k + 1];
+                const double wk1 = pw;
                 const double sdk = gs * wk + gc * sk;
                 const double dkp1 = gs * sk + gc * wk1;
                 const double nwk = gc * (gc * wk - gs * sk) - gs * (gc * sk - gs * wk1);
@@ -222,19 +238,20 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
                 if (k > start) nskm1 = gc * skm1 - gs * z;
                 x = nsk;
                 double nsk1 = 0.0;
-                if (k < end - 1) { const double sk1 = L.sub[k + 1]; z = -gs * sk1; nsk1 = gc * sk1; }
+                if (k < end - 1) { const double sk1 = ps; z = -gs * sk1; nsk1 = gc * sk1; }
                 if (lane == 0) {
                     L.w[k] = nwk; L.w[k + 1] = nwk1; L.sub[k] = nsk;
                     if (k > start) L.sub[k - 1] = nskm1;
                     if (k < end - 1) L.sub[k + 1] = nsk1;
                 }
-                for (int i = lane; i < n; i += 64) {        // q.applyOnTheRight(k, k + 1, rot)
-                    const double xi = E(i, k), yi = E(i, k + 1);
-                    E(i, k) = gc * xi - gs * yi;
-                    E(i, k + 1) = gs * xi + gc * yi;
-                }
+                // q.applyOnTheRight(k, k + 1, rot): column k is final, column k + 1 stays in the register
+                if (ha) { E(ia, k) = gc * qa - gs * na; qa = gs * qa + gc * na; na = fa; }
+                if (hb) { E(ib, k) = gc * qb - gs * nb; qb = gs * qb + gc * nb; nb = fb; }
                 wk = nwk1; sk = nsk1; skm1 = nsk;
+                pw = fw; ps = fsub;
             }
+            if (ha) E(ia, k) = qa;
+            if (hb) E(ib, k) = qb;
             FS_SYNC();
         }
         if (iter <= 30 * n) {
@@ -273,6 +290,7 @@ GPIS_DEV void fs_pinv(FsLds &L, int n, int lane)
     for (int i = lane; i < n; i += 64)
         for (int j = 0; j < n; ++j) {
             double s = 0.0;
+            #pragma unroll 8
             for (int k = 0; k < n; ++k) s += U[k * n + i] * U[k * n + j];
             A[j * n + i] = s;
         }
@@ -298,6 +316,7 @@ GPIS_DEV void fs_norm_transform(FsLds &L, int n, int lane)
         if (lane == 0) LL(k, k) = x;
         for (int i = k + 1 + lane; i < n; i += 64) {
             double s = LL(i, k);
+            #pragma unroll 8
             for (int j = 0; j < k; ++j) s -= LL(i, j) * LL(k, j);
             LL(i, k) = s / x;
         }
@@ -382,6 +401,7 @@ GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, int n, int nc, V3d der
         for (int i = lane; i < nc; i += 64)
             for (int j = 0; j < n; ++j) {
                 double acc = 0.0;
+                #pragma unroll 8
                 for (int k = 0; k < nc; ++k) acc += s11[k * nc + i] * s12[j * nc + k];
                 sol[j * nc + i] = acc;
             }
@@ -393,6 +413,7 @@ GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, int n, int nc, V3d der
             L.mean[i] += acc;
             for (int j = 0; j < n; ++j) {
                 double a2 = 0.0;
+                #pragma unroll 8
                 for (int k = 0; k < nc; ++k) a2 += sol[i * nc + k] * s12[j * nc + k];
                 S[j * n + i] -= a2;
             }
@@ -415,6 +436,7 @@ GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, int n, int nc, V3d der
     const double *T = L.B1;
     for (int i = lane; i < n; i += 64) {
         double acc = 0.0;
+        #pragma unroll 8
         for (int j = 0; j < n; ++j) acc += T[j * n + i] * L.z[j];
         L.vals[i] = L.mean[i] + acc;
     }
