@@ -61,14 +61,20 @@ def issue_roofline(kernel, workload_key, avg_launch_ms, lib_path):
     peak     = 1024 SIMDs x 2.4 GHz: every SIMD issuing on every cycle of the launch (the launch cannot use more).
     The counters belong to one launch of the SAME workload with the SAME library (sha256 compared); they are
     deterministic for it.  `traffic` = FETCH_SIZE + WRITE_SIZE of the same launch."""
-    if not os.path.exists(ISSUE_MODEL):
+    import glob
+    model, k, src = None, None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_issue_model*.json"))):     # one file per profiled workload
+        try:
+            cand = json.load(open(path))
+        except Exception:
+            continue
+        model = model or cand
+        if cand.get("workload") == workload_key and kernel in cand.get("kernels", {}):
+            model, k, src = cand, cand["kernels"][kernel], os.path.relpath(path, ROOT)
+            break
+    if model is None:
         return None
-    try:
-        model = json.load(open(ISSUE_MODEL))
-    except Exception:
-        return None
-    k = model.get("kernels", {}).get(kernel)
-    if k is None or model.get("workload") != workload_key:
+    if k is None:
         return {"bound": "valu_issue", "kernel": kernel, "achieved": None, "peak": N_SIMD * PEAK_CLOCK_HZ / 1e12, "unit": "T SIMD issue cycles/s",
                 "frac": None, "traffic": None, "note": "no committed instruction counters for this kernel / workload (%s)" % workload_key}
     stale = model.get("so_sha256") != library_sha256(lib_path)
@@ -87,7 +93,7 @@ def issue_roofline(kernel, workload_key, avg_launch_ms, lib_path):
         "mean_cycles_per_valu_instruction": cyc["model"] / max(k["valu_insts"], 1),
         "fit": {"relative_residual": k["fit"]["relative_residual"], "loops_used": k["fit"]["loops_used"]} if k.get("fit") else None,
         "avg_launch_ms": avg_launch_ms, "profiled_launch_ms": k.get("launch_ms_profiled"),
-        "counters_source": "profiles/r02_issue_model.json (" + model.get("collected", "") + ")", "counters_stale": stale,
+        "counters_source": src + " (" + model.get("collected", "") + ")", "counters_stale": stale,
     }
 
 

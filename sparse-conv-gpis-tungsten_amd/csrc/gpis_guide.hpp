@@ -52,9 +52,10 @@ struct GuideField {
 
 #ifndef GPIS_GUIDE_OCC
 // waves per SIMD the guided kernels are register-allocated for.  Guide lookups are latency-bound, so
-// occupancy beats spill-free code here: measured on C1 960x540x64 (sd+tr ms) occ2 180 (no spills),
-// occ3 149, occ4 137, occ5 146, occ6 154, occ8 183
-#define GPIS_GUIDE_OCC 4
+// occupancy beats spill-free code here: measured on C1 960x540x64 (sd+tr ms, round 1) occ2 180 (no spills),
+// occ3 149, occ4 137, occ5 146, occ6 154, occ8 183.  Round 2, after the path functions the cold fallback inlines were pinned to
+// their 3D-stationary instance (scratch 320 -> 208 B): whole C1 frames, sd ms at 3 waves 282.5, 4 waves 244.7, 5 waves 232.1
+#define GPIS_GUIDE_OCC 5
 #endif
 #ifndef GPIS_GUIDE_OCC_TR
 // transmittance carries less state (no lastVal / gradient tail): whole C1 frames, sd / tr ms at 3 waves 336 / 135,
