@@ -13,6 +13,8 @@ ISA=/tmp/gpis_hip_final.s
 CL1="SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
 CL2="SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU"
 CL3="SQ_WAVES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
+PART=${1:-a}
+if [ $PART = a ]; then
 # ---- C1 (headline): counters first, model, then the bench lines that read it
 i=0
 for C in "$CL1" "$CL2" "$CL3" "FETCH_SIZE" "WRITE_SIZE"; do
@@ -21,6 +23,10 @@ for C in "$CL1" "$CL2" "$CL3" "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python tools/make_issue_model.py --workload "C1 1920x1080x64 guide 16:64 n_gpus 1" --collected "rocprofv3 --kernel-trace --pmc <class counters | FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --no-cpu-baseline --no-unguided --steps 1 --warmup 0 (tools/gpu_session10.sh)" \
    --isa $ISA --out profiles/r02_issue_model_C1.json $O/c1_pmc*/pmc_results.db > $O/model_C1.log 2>&1; echo "model C1 rc=$?"; tail -3 $O/model_C1.log
+timeout -k 10 500 python bench.py > $O/bench_C1.json 2> $O/bench_C1.err; echo "bench C1 (default command) rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o c1 -- python3 bench.py --no-cpu-baseline --no-unguided --steps 3 --warmup 1 > $O/bench_C1_under_rocprof.json 2> $O/prof_c1.log; echo "rocprof C1 rc=$?"
+cp profiles/r02_issue_model_C1.json $O/
+else
 # ---- C3 at its own density (persistent refilling march), 480x270x8
 SZ3="--config C3 --guide off --width 480 --height 270 --spp 8"
 i=0
@@ -41,14 +47,13 @@ python tools/make_issue_model.py --workload "C2 1920x1080x16 guide off n_gpus 1"
    --isa $ISA --out profiles/r02_issue_model_C2.json $O/c2_pmc*/pmc_results.db > $O/model_C2.log 2>&1; echo "model C2 rc=$?"; tail -3 $O/model_C2.log
 cp profiles/r02_issue_model_C*.json $O/
 # ---- bench lines (now with the roofline block filled) and the kernel-trace summaries of the same commands
-timeout -k 10 500 python bench.py > $O/bench_C1.json 2> $O/bench_C1.err; echo "bench C1 (default command) rc=$?"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o c1 -- python3 bench.py --no-cpu-baseline --no-unguided --steps 3 --warmup 1 > $O/bench_C1_under_rocprof.json 2> $O/prof_c1.log; echo "rocprof C1 rc=$?"
 timeout -k 10 300 python bench.py $SZ3 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C3.json 2> $O/bench_C3.err; echo "bench C3 rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o c3 -- python3 bench.py $SZ3 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C3_under_rocprof.json 2> $O/prof_c3.log; echo "rocprof C3 rc=$?"
 timeout -k 10 300 python bench.py $SZ2 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C2.json 2> $O/bench_C2.err; echo "bench C2 rc=$?"
 timeout -k 10 300 python bench.py --config C0 --width 256 --height 256 --spp 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_C0.json 2> $O/bench_C0.err; echo "bench C0 rc=$?"
 timeout -k 10 300 python tools/host_path_bench.py > $O/host_path.json 2> $O/host_path.err; echo "host path rc=$?"
 timeout -k 10 300 python tools/fs_bench.py > $O/fs_bench.json 2> $O/fs_bench.err; echo "fs bench rc=$?"
+fi
 find $O -name "*stats*.csv" -o -name "*kernel_trace.csv" | head; du -sh $O
 python - <<PY
 import json, glob
