@@ -85,7 +85,9 @@ def issue_roofline(kernel, workload_key, avg_launch_ms, lib_path):
     return {
         "bound": "valu_issue", "kernel": kernel,
         "achieved": cyc["model"] / sec / 1e12, "peak": peak / 1e12, "unit": "T SIMD issue cycles/s",
-        "frac": cyc["model"] / sec / peak, "frac_range": [cyc["lo"] / sec / peak, (cyc["hi"] / sec / peak) if cyc.get("hi") else None],
+        "frac": cyc["model"] / sec / peak, # lo: every instruction at the full rate except the classes whose cost is known exactly; hi: SQ_ACTIVE_INST_VALU x 4, a
+        # counter with 4-cycle granularity that also charges 4 cycles to a 2-cycle instruction — an upper bound, capped at the roof
+        "frac_range": [cyc["lo"] / sec / peak, min(1.0, cyc["hi"] / sec / peak) if cyc.get("hi") else None],
         "traffic": traffic,
         "hbm": None if traffic is None else {"bytes_per_launch": traffic, "GBps": traffic / sec / 1e9, "frac_of_peak": traffic / sec / 1e9 / HBM_PEAK_GBS,
                                               "compulsory_bytes_per_launch": k.get("compulsory_bytes")},
