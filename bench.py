@@ -41,12 +41,16 @@ def algorithmic_bytes_per_eval(params):
     return (3 * rho * 8 * L) if params["sampling_1d"] else (27 * rho * 16 * L)
 
 
-def library_sha256(path):
+def sources_sha256():
+    """Identity of the kernels the committed counters belong to: sha256 over the HIP sources and the ABI header (the built .so
+    embeds build paths, so its own hash differs between two builds of the same code)."""
     import hashlib
+    csrc = os.path.join(ROOT, "sparse-conv-gpis-tungsten_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc"))) + [os.path.join(ROOT, "include", "gpis.h")]
     h = hashlib.sha256()
-    with open(path, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 20), b""):
-            h.update(blk)
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()
 
 
@@ -77,7 +81,7 @@ def issue_roofline(kernel, workload_key, avg_launch_ms, lib_path):
     if k is None:
         return {"bound": "valu_issue", "kernel": kernel, "achieved": None, "peak": N_SIMD * PEAK_CLOCK_HZ / 1e12, "unit": "T SIMD issue cycles/s",
                 "frac": None, "traffic": None, "note": "no committed instruction counters for this kernel / workload (%s)" % workload_key}
-    stale = model.get("so_sha256") != library_sha256(lib_path)
+    stale = model.get("source_sha256") != sources_sha256()
     sec = avg_launch_ms * 1e-3
     peak = N_SIMD * PEAK_CLOCK_HZ
     cyc = k["issue_cycles"]

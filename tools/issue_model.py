@@ -165,7 +165,11 @@ def model(groups, costs, counters, ms, clock_hz=PEAK_CLOCK_HZ):
     total = counters["SQ_INSTS_VALU"]
     b = np.array([counters.get("SQ_INSTS_VALU_" + k, 0.0) for k in CLASSES] + [total])
     scale = 1.0 / np.maximum(b, 1e-6 * total)
+    scale[-1] *= 4.0                     # the total instruction count is the best-known of the 12 numbers
     w, resid = nnls(A * scale[:, None], b * scale)
+    pred_total = float((A @ w)[-1])
+    if pred_total > 0:
+        w = w * (total / pred_total)     # the fitted mix, scaled to exactly the counted number of instructions
     fit = float(cost_g @ w)
     pred = A @ w
     # floor: every instruction costs at least 2 cycles; the homogeneous classes are known exactly
@@ -173,6 +177,8 @@ def model(groups, costs, counters, ms, clock_hz=PEAK_CLOCK_HZ):
     n_known = sum(counters.get("SQ_INSTS_VALU_" + k, 0.0) for k in HOMOGENEOUS)
     lo = known + 2.0 * (total - n_known)
     hi = counters.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 or None
+    if hi:
+        fit = min(fit, hi)               # the counter-based ceiling binds when the per-mnemonic costs over-price a mix
     avail = ms * 1e-3 * clock_hz * N_SIMD
     top = sorted(range(len(G)), key=lambda j: -w[j] * cost_g[j])[:6]
     return {"issue_cycles": {"lo": lo, "model": fit, "hi": hi}, "simd_cycles_available": avail,

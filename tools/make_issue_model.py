@@ -86,7 +86,10 @@ def main():
                                "-I", CSRC, "-S", "--cuda-device-only", "-o", isa, os.path.join(CSRC, "gpis_hip.hip")], stderr=subprocess.DEVNULL)
     costs, _ = im.cost_table(args.micro)
     compulsory = json.load(open(args.compulsory)) if args.compulsory else {}
-    out = {"workload": args.workload, "collected": args.collected, "so_sha256": hashlib.sha256(open(args.library, "rb").read()).hexdigest(),
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {"workload": args.workload, "collected": args.collected, "source_sha256": bench.sources_sha256(),
+           "so_sha256_of_the_profiled_build": hashlib.sha256(open(args.library, "rb").read()).hexdigest(),
            "n_simd": im.N_SIMD, "clock_hz_peak": im.PEAK_CLOCK_HZ, "issue_costs": os.path.relpath(args.micro, ROOT), "kernels": {}}
     for kname, cs in counters.items():
         key = bench_key(kname)
