@@ -1,0 +1,54 @@
+"""Register / scratch / LDS budget of the hot kernels, read from the code object inside libgpis_hip.so (no GPU needed).
+Round 2 lost half of the C1 rate for a while because the guided kernel's cold fallback resolved to the all-features instance of
+the path section and its scratch grew from 320 to 668 B per lane: this test is the tripwire for that class of regression."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernels(lib):
+    tmp = tempfile.mkdtemp()
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
+        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True, stderr=subprocess.DEVNULL)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for blk in notes.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if name:
+            out[name.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+                                  for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "group_segment_fixed_size")}
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="LLVM tools of the ROCm image")
+def test_hot_kernels_keep_their_budget(pkg):
+    k = _kernels(pkg.library_path())
+
+    def one(sub):
+        hits = [v for n, v in k.items() if sub in n]
+        assert hits, sub
+        return hits
+
+    for v in one("k_guided_sample_distanceILb"):          # allocated for 5 waves/SIMD: 96 VGPRs, a few hundred bytes of scratch
+        assert v["vgpr_count"] <= 96 and v["private_segment_fixed_size"] <= 400, v
+    for v in one("k_guided_transmittanceILb"):
+        assert v["vgpr_count"] <= 96 and v["private_segment_fixed_size"] <= 360, v
+    for v in one("k_fast_sample_distance"):
+        assert v["private_segment_fixed_size"] == 0, v
+    for sub, scratch in (("spec_3d7PersistE", 0), ("16spec_3d_multires7PersistE", 64), ("spec_1d7PersistE", 160)):
+        for v in one("k_persist_marchIN4gpis" + ("7" if not sub[0].isdigit() else "") + sub):
+            assert v["vgpr_count"] <= 168 and v["private_segment_fixed_size"] <= scratch, (sub, v)   # 3 waves/SIMD
+            assert v["group_segment_fixed_size"] <= 16 * 1024
+    for v in one("k_fs_marchILb"):                        # one CU's LDS, no scratch
+        assert v["group_segment_fixed_size"] <= 160 * 1024 and v["private_segment_fixed_size"] == 0, v
