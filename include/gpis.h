@@ -367,7 +367,8 @@ int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, fl
 
 /* Medium::sampleDistance / transmittance of the function-space medium (GaussianProcessMedium.cpp:221-393 over
  * FunctionSpaceGaussianProcessMedium::intersectGP / sampleGradient).  rays[i].u_jitter is not used (every variate comes from
- * states[i].sampler_state); states are read and written in place (device pointers). */
+ * states[i].sampler_state); states are read and written in place (device pointers).  The two entries share one device
+ * workspace per handle: launches of the SAME handle must be ordered (one stream, or an event between them). */
 int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream);
 int gpis_fs_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible, void *stream);
 

@@ -1,4 +1,4 @@
-// gpis_fs.hpp — the function-space comparison path on one wave per segment.
+// gpis_fs.hpp — the function-space comparison path: one wave per segment, four segments per CU.
 //
 //   FunctionSpaceGaussianProcessMedium::intersectGP / sampleGradient   media/FunctionSpaceGaussianProcessMedium.cpp:58-345
 //   GPRealNodeValues::{makeIntersect, sampleGrad, applyMemory}          math/GaussianProcess.cpp:76-168
@@ -10,11 +10,13 @@
 //
 // One segment = (64 + c)^2 doubles of dense linear algebra (c <= 66 conditioning entries): covariance build, a symmetric
 // eigen-decomposition for the pseudo-inverse, two matrix products, a Cholesky factorisation (or a second eigen-decomposition
-// when it fails — the rule for squared-exponential covariances on a fine grid), 64 normal variates.  All of it lives in the
-// 160 KB of LDS of one CU (146 KB used: one workgroup of one wave per CU) in fp64; lane = matrix row, inner sums run serially
-// in ascending index order inside each lane, so every value is produced by the same sequence of IEEE operations as in the
-// CPU restatement (exp / log / sin / cos excepted).  No MFMA: the products are 66 x 66 x 64 fp64 with a data-dependent
-// factorisation between them.
+// when it fails — the rule for squared-exponential covariances on a fine grid), 64 normal variates, in fp64.  90 % of the time
+// is the eigen-solver's serial phases (Householder tridiagonalisation, implicit-QR bulge chase: ~650 cycles of dependent fp64
+// division / square root per rotation), so the matrix being factorised and the solver's vectors sit in LDS (37 KB) and FOUR
+// one-wave workgroups — one per SIMD — share a CU; the matrices that are only touched in bulk live in a per-workgroup slice of
+// a global workspace (L2).  Lane = matrix row, inner sums run serially in ascending index order inside each lane, so every value
+// is produced by the same sequence of IEEE operations as in the CPU restatement (exp / log / sin / cos excepted).  No MFMA:
+// the products are 66 x 66 x 64 fp64 (< 10 % of the time) between data-dependent factorisations.
 #pragma once
 #include "gpis_device.hpp"
 
@@ -25,19 +27,34 @@ namespace gpis {
 constexpr int kFsN = GPIS_FS_MAX_POINTS, kFsC = GPIS_FS_MAX_CTX;
 constexpr int FS_NONE = 0, FS_FIRST = 1;
 
+// The matrix being factorised and the vectors of the eigen-solver live in LDS (37 KB: four workgroups — one wave per SIMD — per
+// CU); everything that is only touched in bulk (the other three matrices, point lists, sample vectors) lives in a per-workgroup
+// slice of a global workspace that stays in L2.  The serial phases (tridiagonalisation, bulge chase: 90 % of the time) only see LDS.
 struct FsLds {
     double B1[kFsC * kFsC];      // s11 -> its eigenvectors -> its pseudo-inverse; later the normal transform T
+    double w[kFsC], sub[kFsC], hco[kFsC], hv[kFsC], tmp[kFsC];
+};
+struct FsGlob {
     double B2[kFsC * kFsC];      // scaled eigenvectors; later (pinv * s12)
     double B3[kFsC * kFsN];      // s12
     double B4[kFsN * kFsN];      // s22 -> conditional covariance
-    double w[kFsC], sub[kFsC], hco[kFsC], hv[kFsC], tmp[kFsC];
     double mean[kFsC], z[kFsC], vals[kFsC], cv[kFsC], resid[kFsC], ts[kFsN];
     double pts[kFsC][3], cpts[kFsC][3], dirs[3][3];
     int der[kFsC], cder[kFsC];
 };
-static_assert(sizeof(FsLds) <= 160 * 1024, "the function-space workspace must fit the LDS of one CU");
+static_assert(sizeof(FsLds) <= 40 * 1024, "four function-space workgroups share the LDS of one CU");
 
 #define FS_SYNC() __syncthreads()
+
+// -DGPIS_FS_PROF (diagnostic builds only): wave cycles per phase, read back with gpis_fs_prof_read
+#ifdef GPIS_FS_PROF
+__device__ unsigned long long g_fs_prof[16];
+#define FS_T0() const long long fs_t0_ = (long long)__builtin_readcyclecounter()
+#define FS_T(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fs_prof[i], (unsigned long long)((long long)__builtin_readcyclecounter() - fs_t0_)); } while (0)
+#else
+#define FS_T0() do { } while (0)
+#define FS_T(i) do { } while (0)
+#endif
 
 GPIS_DEV double fs_dot(V3d a, V3d b) { double r = a.x * b.x; r += a.y * b.y; r += a.z * b.z; return r; }
 GPIS_DEV V3d fs_v3(const double *p) { return V3d{p[0], p[1], p[2]}; }
@@ -93,6 +110,7 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
     for (int i = lane; i < n; i += 64)
         for (int j = 0; j <= i; ++j) E(i, j) /= scale;
     FS_SYNC();
+    { FS_T0();
     for (int i = 0; i < n - 1; ++i) {                       // tridiagonalization_inplace, Tridiagonalization.h:352-383
         const int rs = n - i - 1;
         double tailSq = 0.0;
@@ -139,11 +157,13 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
         if (lane == 0) { E(i + 1, i) = beta; L.hco[i] = h; }
         FS_SYNC();
     }
+    FS_T(0); }
     for (int k = lane; k < n; k += 64) {
         L.w[k] = E(k, k);
         if (k < n - 1) L.sub[k] = E(k + 1, k);
     }
     FS_SYNC();
+    { FS_T0();
     // Q = HouseholderSequence(mat, hCoeffs).setLength(n - 1).setShift(1), evaluated in place (HouseholderSequence.h:293-318)
     for (int r = lane; r < n; r += 64) {
         E(r, r) = 1.0;
@@ -174,7 +194,9 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
         for (int r = k + 1 + lane; r < n; r += 64) E(r, k) = 0.0;
         FS_SYNC();
     }
+    FS_T(1); }
     {   // computeFromTridiagonal_impl (m_maxIterations = 30), SelfAdjointEigenSolver.h:504-579, tridiagonal_qr_step :841-900
+        FS_T0();
         int end = n - 1, start = 0, iter = 0;
         const double considerAsZero = 2.2250738585072014e-308, precision_inv = 1.0 / 2.220446049250313e-16;
         while (end > 0) {
@@ -254,7 +276,9 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
             if (hb) E(ib, k) = qb;
             FS_SYNC();
         }
+        FS_T(2);
         if (iter <= 30 * n) {
+            FS_T0();
             for (int i = 0; i < n - 1; ++i) {
                 int k = 0;
                 for (int j = 1; j < n - i; ++j) if (L.w[i + j] < L.w[i + k]) k = j;
@@ -265,6 +289,7 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
                 }
                 FS_SYNC();
             }
+            FS_T(3);
         }
     }
     for (int k = lane; k < n; k += 64) L.w[k] *= scale;
@@ -273,13 +298,14 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
 }
 
 // pseudo_inverse, GaussianProcess.cpp:645-662: A (n x n in B1) is replaced by its pseudo-inverse; B2 is scratch
-GPIS_DEV void fs_pinv(FsLds &L, int n, int lane)
+GPIS_DEV void fs_pinv(FsLds &L, FsGlob &G, int n, int lane)
 {
-    double *A = L.B1, *U = L.B2;
+    double *A = L.B1, *U = G.B2;
     fs_eigh(L, n, A, lane);
     double mx = 0.0;
     for (int i = 0; i < n; ++i) { const double v = fabs(L.w[i]); if (v > mx) mx = v; }
     const double eps = 1e6 * 2.220446049250313e-16 * mx;
+    FS_T0();
     for (int i = lane; i < n; i += 64)
         for (int k = 0; k < n; ++k) {
             const double wk = L.w[k];
@@ -295,17 +321,19 @@ GPIS_DEV void fs_pinv(FsLds &L, int n, int lane)
             A[j * n + i] = s;
         }
     FS_SYNC();
+    FS_T(4);
 }
 
 // normTransform of MultivariateNormalDistribution, Gaussian.cpp:121-167: S (n x n in B4) -> T (in B1)
-GPIS_DEV void fs_norm_transform(FsLds &L, int n, int lane)
+GPIS_DEV void fs_norm_transform(FsLds &L, FsGlob &G, int n, int lane)
 {
-    const double *S = L.B4;
+    const double *S = G.B4;
     double *T = L.B1;
     for (int i = lane; i < n; i += 64)
         for (int j = 0; j < n; ++j) T[j * n + i] = S[j * n + i];
     FS_SYNC();
     bool ok = true;
+    FS_T0();
 #define LL(i, j) T[(j) * n + (i)]
     for (int k = 0; k < n; ++k) {                           // LLT (Cholesky/LLT.h): a pivot x <= 0 is the failure
         double x = LL(k, k);
@@ -323,6 +351,7 @@ GPIS_DEV void fs_norm_transform(FsLds &L, int n, int lane)
         FS_SYNC();
     }
     FS_SYNC();
+    FS_T(8);
     if (ok) {
         for (int i = lane; i < n; i += 64)
             for (int j = i + 1; j < n; ++j) LL(i, j) = 0.0;
@@ -371,33 +400,38 @@ GPIS_DEV double fs_rand_truncated_normal(double mean, double sigma, double a, Pc
 }
 
 // GaussianProcess::sample / sample_cond -> create_mvn_cond -> MultivariateNormalDistribution::sample (one sample), with
-// L.pts / L.der (+ L.dirs when has_dirs) the n target entries and L.cpts / L.cder / L.cv the nc conditioning entries.
-// Result in L.vals[0 .. n).  GaussianProcess.cpp:605-632, 664-753; Gaussian.cpp:179-232.
-GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, int n, int nc, V3d deriv_dir, bool has_dirs, Pcg32 &s, int lane)
+// G.pts / G.der (+ G.dirs when has_dirs) the n target entries and G.cpts / G.cder / G.cv the nc conditioning entries.
+// Result in G.vals[0 .. n).  GaussianProcess.cpp:605-632, 664-753; Gaussian.cpp:179-232.
+GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, FsGlob &G, int n, int nc, V3d deriv_dir, bool has_dirs, Pcg32 &s, int lane)
 {
-    double *S = L.B4, *s11 = L.B1, *s12 = L.B3, *sol = L.B2;
-    auto dir_of = [&](int i) { return has_dirs ? fs_v3(L.dirs[i]) : deriv_dir; };
+    double *S = G.B4, *s11 = L.B1, *s12 = G.B3, *sol = G.B2;
+    auto dir_of = [&](int i) { return has_dirs ? fs_v3(G.dirs[i]) : deriv_dir; };
+    { FS_T0();
     for (int i = lane; i < n; i += 64) {
-        L.mean[i] = fs_mean(M, L.der[i], fs_v3(L.pts[i]), dir_of(i));
+        G.mean[i] = fs_mean(M, G.der[i], fs_v3(G.pts[i]), dir_of(i));
         for (int j = 0; j <= i; ++j) {
-            const double c = fs_cov(M, L.der[i], L.der[j], fs_v3(L.pts[i]), fs_v3(L.pts[j]), dir_of(i), dir_of(j));
+            const double c = fs_cov(M, G.der[i], G.der[j], fs_v3(G.pts[i]), fs_v3(G.pts[j]), dir_of(i), dir_of(j));
             S[j * n + i] = c;
             S[i * n + j] = c;
         }
     }
     FS_SYNC();
+    FS_T(5); }
     if (nc > 0) {
+        { FS_T0();
         for (int i = lane; i < nc; i += 64)
             for (int j = 0; j <= i; ++j) {
-                const double c = fs_cov(M, L.cder[i], L.cder[j], fs_v3(L.cpts[i]), fs_v3(L.cpts[j]), deriv_dir, deriv_dir);
+                const double c = fs_cov(M, G.cder[i], G.cder[j], fs_v3(G.cpts[i]), fs_v3(G.cpts[j]), deriv_dir, deriv_dir);
                 s11[j * nc + i] = c;
                 s11[i * nc + j] = c;
             }
         for (int j = lane; j < n; j += 64)
             for (int i = 0; i < nc; ++i)
-                s12[j * nc + i] = fs_cov(M, L.cder[i], L.der[j], fs_v3(L.cpts[i]), fs_v3(L.pts[j]), deriv_dir, dir_of(j));
+                s12[j * nc + i] = fs_cov(M, G.cder[i], G.der[j], fs_v3(G.cpts[i]), fs_v3(G.pts[j]), deriv_dir, dir_of(j));
         FS_SYNC();
-        fs_pinv(L, nc, lane);
+        FS_T(5); }
+        fs_pinv(L, G, nc, lane);
+        FS_T0();
         for (int i = lane; i < nc; i += 64)
             for (int j = 0; j < n; ++j) {
                 double acc = 0.0;
@@ -405,12 +439,13 @@ GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, int n, int nc, V3d der
                 for (int k = 0; k < nc; ++k) acc += s11[k * nc + i] * s12[j * nc + k];
                 sol[j * nc + i] = acc;
             }
-        for (int k = lane; k < nc; k += 64) L.resid[k] = L.cv[k] - fs_mean(M, L.cder[k], fs_v3(L.cpts[k]), deriv_dir);
+        for (int k = lane; k < nc; k += 64) G.resid[k] = G.cv[k] - fs_mean(M, G.cder[k], fs_v3(G.cpts[k]), deriv_dir);
         FS_SYNC();
+        FS_T(6);
         for (int i = lane; i < n; i += 64) {
             double acc = 0.0;
-            for (int k = 0; k < nc; ++k) acc += sol[i * nc + k] * L.resid[k];
-            L.mean[i] += acc;
+            for (int k = 0; k < nc; ++k) acc += sol[i * nc + k] * G.resid[k];
+            G.mean[i] += acc;
             for (int j = 0; j < n; ++j) {
                 double a2 = 0.0;
                 #pragma unroll 8
@@ -419,28 +454,31 @@ GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, int n, int nc, V3d der
             }
         }
         FS_SYNC();
+        FS_T(7);
     }
-    fs_norm_transform(L, n, lane);
+    fs_norm_transform(L, G, n, lane);
+    FS_T0();
     // the variates: every lane advances its copy of the sampler identically
     for (int i = 0; i < n / 2; i++) {
         double a, b;
         rand_normal_2(s, a, b);
-        if (lane == 0) { L.z[i * 2] = a; L.z[i * 2 + 1] = b; }
+        if (lane == 0) { G.z[i * 2] = a; G.z[i * 2 + 1] = b; }
     }
     if (n % 2) {
         double a, b;
         rand_normal_2(s, a, b);
-        if (lane == 0) L.z[n - 1] = a;
+        if (lane == 0) G.z[n - 1] = a;
     }
     FS_SYNC();
     const double *T = L.B1;
     for (int i = lane; i < n; i += 64) {
         double acc = 0.0;
         #pragma unroll 8
-        for (int j = 0; j < n; ++j) acc += T[j * n + i] * L.z[j];
-        L.vals[i] = L.mean[i] + acc;
+        for (int j = 0; j < n; ++j) acc += T[j * n + i] * G.z[j];
+        G.vals[i] = G.mean[i] + acc;
     }
     FS_SYNC();
+    FS_T(9);
 }
 
 // TangentFrameD(n), TangentFrame.hpp:28-37
@@ -455,7 +493,7 @@ GPIS_DEV void fs_frame(V3d n, V3d &tangent, V3d &bitangent)
 
 // FunctionSpaceGaussianProcessMedium::intersectGP, FunctionSpace...cpp:58-282 (skip_space = 0).  The state record lives in
 // global memory and is rewritten on return; wave-uniform result.
-GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, Pcg32 &s, V3 pos, V3 dir, float ray_near, float ray_far, bool first_scatter,
+GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, FsGlob &G, Pcg32 &s, V3 pos, V3 dir, float ray_near, float ray_far, bool first_scatter,
                               bool firstIsectAlongRay, gpis_fs_state *st, int &last_gp_id, double &t_out, int lane)
 {
     const int n = M.fs_n;
@@ -476,10 +514,10 @@ GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, Pcg32 &s, V3 pos, V3 
         double rt = lerp_d((double)ray_near + step * 0.1, (double)ray_near + maxRayDist, r);
         if (i == 0) rt = nearT + step * 0.1;
         else if (i == n - 1) rt = nearT + maxRayDist;
-        L.ts[i] = rt;
+        G.ts[i] = rt;
         const V3d p = ray_at(ro, rd, rt);
-        L.pts[i][0] = p.x; L.pts[i][1] = p.y; L.pts[i][2] = p.z;
-        L.der[i] = FS_NONE;
+        G.pts[i][0] = p.x; G.pts[i][1] = p.y; G.pts[i][2] = p.z;
+        G.der[i] = FS_NONE;
     }
     const bool conditioned = !first_scatter && st->has_context;
     if (conditioned && st->n_points == 0)
@@ -499,34 +537,34 @@ GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, Pcg32 &s, V3 pos, V3 
         if (M.ctx == GPIS_CTX_RENEWAL || M.ctx == GPIS_CTX_RENEWAL_PLUS) {
             nc = M.ctx == GPIS_CTX_RENEWAL ? 1 : 2;
             if (lane < nc) {
-                L.cpts[lane][0] = last.x; L.cpts[lane][1] = last.y; L.cpts[lane][2] = last.z;
-                L.cder[lane] = lane == 0 ? FS_NONE : FS_FIRST;
-                L.cv[lane] = lane == 0 ? v_last : sg_rd;
+                G.cpts[lane][0] = last.x; G.cpts[lane][1] = last.y; G.cpts[lane][2] = last.z;
+                G.cder[lane] = lane == 0 ? FS_NONE : FS_FIRST;
+                G.cv[lane] = lane == 0 ? v_last : sg_rd;
             }
         } else if (M.ctx == GPIS_CTX_GLOBAL) {
             nc = np;
             for (int i = lane; i < nc; i += 64) {
-                L.cpts[i][0] = st->points[i][0]; L.cpts[i][1] = st->points[i][1]; L.cpts[i][2] = st->points[i][2];
-                L.cder[i] = st->derivs[i];
-                L.cv[i] = st->values[i];
+                G.cpts[i][0] = st->points[i][0]; G.cpts[i][1] = st->points[i][1]; G.cpts[i][2] = st->points[i][2];
+                G.cder[i] = st->derivs[i];
+                G.cv[i] = st->values[i];
             }
             FS_SYNC();
             if (!st->is_intersect) {
-                if (lane == 0) { L.cpts[nc][0] = last.x; L.cpts[nc][1] = last.y; L.cpts[nc][2] = last.z; L.cder[nc] = FS_FIRST; }
+                if (lane == 0) { G.cpts[nc][0] = last.x; G.cpts[nc][1] = last.y; G.cpts[nc][2] = last.z; G.cder[nc] = FS_FIRST; }
                 nc++;
             }
             FS_SYNC();
-            if (lane == 0) L.cv[nc - 1] = sg_rd;
+            if (lane == 0) G.cv[nc - 1] = sg_rd;
         }
     }
     FS_SYNC();
-    fs_sample_cond(M, L, n, nc, rd, false, s, lane);
+    fs_sample_cond(M, L, G, n, nc, rd, false, s, lane);
     // the march over the sampled values (every lane walks the same array)
-    double prevV = L.vals[0];
+    double prevV = G.vals[0];
     int sign0 = prevV < 0 ? -1 : 1;
-    double prevT = L.ts[0];
+    double prevT = G.ts[0];
     for (int p = 1; p < n; p++) {
-        const double currV = L.vals[p], currT = L.ts[p];
+        const double currV = G.vals[p], currT = G.ts[p];
         const int signc = currV < 0 ? -1 : 1;
         if (!first_scatter && firstIsectAlongRay && p == 1) {
             sign0 = signc;
@@ -536,8 +574,8 @@ GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, Pcg32 &s, V3 pos, V3 
             const V3d ip = ray_at(ro, rd, t);
             FS_SYNC();
             for (int i = lane; i < p + 2; i += 64) {
-                double v = L.vals[i];
-                V3d q = fs_v3(L.pts[i]);
+                double v = G.vals[i];
+                V3d q = fs_v3(G.pts[i]);
                 int dv = FS_NONE;
                 if (i == p) { v = lerp_d(prevV, currV, offsetT); q = ip; }                  // makeIntersect, GaussianProcess.cpp:76-87
                 if (i == p + 1) { v = (prevV - currV) / (prevT - currT); q = ip; dv = FS_FIRST; }
@@ -558,8 +596,8 @@ GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, Pcg32 &s, V3 pos, V3 
     }
     FS_SYNC();
     for (int i = lane; i < n; i += 64) {
-        st->points[i][0] = L.pts[i][0]; st->points[i][1] = L.pts[i][1]; st->points[i][2] = L.pts[i][2];
-        st->derivs[i] = FS_NONE; st->values[i] = L.vals[i];
+        st->points[i][0] = G.pts[i][0]; st->points[i][1] = G.pts[i][1]; st->points[i][2] = G.pts[i][2];
+        st->derivs[i] = FS_NONE; st->values[i] = G.vals[i];
     }
     if (lane == 0) { st->has_context = 1; st->is_intersect = 0; st->n_points = n; st->n_values = n; }
     last_gp_id = 0;
@@ -570,7 +608,7 @@ GPIS_DEV bool fs_intersect_gp(const DevModel &M, FsLds &L, Pcg32 &s, V3 pos, V3 
 }
 
 // sampleGradient (ConditionedGaussian) -> GPRealNodeValues::sampleGrad, FunctionSpace...cpp:284-305, GaussianProcess.cpp:89-132
-GPIS_DEV bool fs_sample_gradient(const DevModel &M, FsLds &L, Pcg32 &s, V3d rd, V3d ip, gpis_fs_state *st, V3d &grad, int lane)
+GPIS_DEV bool fs_sample_gradient(const DevModel &M, FsLds &L, FsGlob &G, Pcg32 &s, V3d rd, V3d ip, gpis_fs_state *st, V3d &grad, int lane)
 {
     if (!st->has_context || st->n_points == 0)
         return false;
@@ -581,19 +619,19 @@ GPIS_DEV bool fs_sample_gradient(const DevModel &M, FsLds &L, Pcg32 &s, V3d rd, 
     const double slope = st->values[nc - 1];
     FS_SYNC();
     for (int i = lane; i < nc; i += 64) {
-        L.cpts[i][0] = st->points[i][0]; L.cpts[i][1] = st->points[i][1]; L.cpts[i][2] = st->points[i][2];
-        L.cder[i] = st->derivs[i];
-        L.cv[i] = st->values[i];
+        G.cpts[i][0] = st->points[i][0]; G.cpts[i][1] = st->points[i][1]; G.cpts[i][2] = st->points[i][2];
+        G.cder[i] = st->derivs[i];
+        G.cv[i] = st->values[i];
     }
     if (lane < 3) {
-        L.pts[lane][0] = ip.x; L.pts[lane][1] = ip.y; L.pts[lane][2] = ip.z;
-        L.der[lane] = FS_FIRST;
+        G.pts[lane][0] = ip.x; G.pts[lane][1] = ip.y; G.pts[lane][2] = ip.z;
+        G.der[lane] = FS_FIRST;
         const V3d d = lane == 0 ? tangent : (lane == 1 ? bitangent : rd);
-        L.dirs[lane][0] = d.x; L.dirs[lane][1] = d.y; L.dirs[lane][2] = d.z;
+        G.dirs[lane][0] = d.x; G.dirs[lane][1] = d.y; G.dirs[lane][2] = d.z;
     }
     FS_SYNC();
-    fs_sample_cond(M, L, isect ? 2 : 3, nc, rd, true, s, lane);
-    const double g0 = L.vals[0], g1 = L.vals[1], g2 = isect ? slope : L.vals[2];
+    fs_sample_cond(M, L, G, isect ? 2 : 3, nc, rd, true, s, lane);
+    const double g0 = G.vals[0], g1 = G.vals[1], g2 = isect ? slope : G.vals[2];
     grad.x = (tangent.x * g0 + bitangent.x * g1) + rd.x * g2;
     grad.y = (tangent.y * g0 + bitangent.y * g1) + rd.y * g2;
     grad.z = (tangent.z * g0 + bitangent.z * g1) + rd.z * g2;
@@ -607,7 +645,7 @@ GPIS_DEV bool fs_sample_gradient(const DevModel &M, FsLds &L, Pcg32 &s, V3d rd, 
 struct FsState { bool first_scatter; int last_gp_id; V3d last_aniso; };
 
 // GaussianProcessMedium::transmittance over the function-space intersectGP, GPM.cpp:343-393 -> exited (false = blocked or failed)
-GPIS_DEV bool fs_transmittance_one(const DevModel &M, FsLds &L, Pcg32 &s, const gpis_ray_in *ray, gpis_fs_state *st, FsState &state, int lane)
+GPIS_DEV bool fs_transmittance_one(const DevModel &M, FsLds &L, FsGlob &G, Pcg32 &s, const gpis_ray_in *ray, gpis_fs_state *st, FsState &state, int lane)
 {
     const V3 pos = v3(ray->pos[0], ray->pos[1], ray->pos[2]), dir = v3(ray->dir[0], ray->dir[1], ray->dir[2]);
     double startT = (double)ray->near_t;
@@ -620,11 +658,11 @@ GPIS_DEV bool fs_transmittance_one(const DevModel &M, FsLds &L, Pcg32 &s, const 
     { const double inv = 1.0 / length_d(rd); rd.x *= inv; rd.y *= inv; rd.z *= inv; }
     bool exited, first = true;
     do {
-        exited = !fs_intersect_gp(M, L, s, pos, dir, (float)startT, farT, state.first_scatter, first, st, state.last_gp_id, t, lane);
+        exited = !fs_intersect_gp(M, L, G, s, pos, dir, (float)startT, farT, state.first_scatter, first, st, state.last_gp_id, t, lane);
         first = false;
         if (t < (double)maxT) {
             V3d grad;
-            if (!fs_sample_gradient(M, L, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane))
+            if (!fs_sample_gradient(M, L, G, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane))
                 return false;
             state.last_aniso = grad;
             state.first_scatter = false;
@@ -638,9 +676,11 @@ GPIS_DEV bool fs_transmittance_one(const DevModel &M, FsLds &L, Pcg32 &s, const 
 
 template <bool WANT_SAMPLE>
 __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp, size_t n_rays, const gpis_ray_in *__restrict__ rays,
-                                                 gpis_fs_state *__restrict__ states, gpis_seg_out *__restrict__ outs, uint8_t *__restrict__ visible)
+                                                 gpis_fs_state *__restrict__ states, gpis_seg_out *__restrict__ outs, uint8_t *__restrict__ visible,
+                                                 FsGlob *__restrict__ workspace)
 {
     __shared__ FsLds L;
+    FsGlob &G = workspace[blockIdx.x];
     const DevModel &M = *Mp;
     const int lane = (int)threadIdx.x;
     for (size_t idx = blockIdx.x; idx < n_rays; idx += gridDim.x) {
@@ -653,8 +693,9 @@ __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp
         state.last_gp_id = ray->last_gp_id;
         state.last_aniso = V3d{ray->last_aniso[0], ray->last_aniso[1], ray->last_aniso[2]};
         FS_SYNC();
+        FS_T0();
         if (!WANT_SAMPLE) {
-            const bool vis = fs_transmittance_one(M, L, s, ray, st, state, lane);
+            const bool vis = fs_transmittance_one(M, L, G, s, ray, st, state, lane);
             if (lane == 0) { visible[idx] = vis ? 1 : 0; st->sampler_state = s.state; }
             continue;
         }
@@ -687,7 +728,7 @@ __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp
                 finished = true;
             } else {
                 o.sample_t = maxT;
-                const bool vis = fs_transmittance_one(M, L, s, ray, st, state, lane);
+                const bool vis = fs_transmittance_one(M, L, G, s, ray, st, state, lane);
                 o.weight[0] = o.weight[1] = o.weight[2] = vis ? 1.f : 0.f;
                 o.exited = 1;
                 o.scheme = GPIS_UNI;
@@ -700,11 +741,11 @@ __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp
             { const double inv = 1.0 / length_d(rd); rd.x *= inv; rd.y *= inv; rd.z *= inv; }
             bool exited, first = true;
             do {
-                exited = !fs_intersect_gp(M, L, s, pos, dir, (float)startT, farT, state.first_scatter, first, st, state.last_gp_id, t, lane);
+                exited = !fs_intersect_gp(M, L, G, s, pos, dir, (float)startT, farT, state.first_scatter, first, st, state.last_gp_id, t, lane);
                 first = false;
                 if (t < (double)maxT) {
                     V3d grad;
-                    if (!fs_sample_gradient(M, L, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane)) {
+                    if (!fs_sample_gradient(M, L, G, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane)) {
                         o.t = t; o.exited = exited; o.ok = 0; o.gp_id = state.last_gp_id;
                         finished = true;
                         break;
@@ -741,7 +782,7 @@ __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp
                     }
                 } else {
                     V3d grad = aniso;
-                    (void)fs_sample_gradient(M, L, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane);   // GPM.cpp:319
+                    (void)fs_sample_gradient(M, L, G, s, to_d(dir), ray_at(ro, rd, t), st, grad, lane);   // GPM.cpp:319
                     aniso = grad;
                     o.weight[0] = o.weight[1] = o.weight[2] = 1.f;
                     o.continued_weight[0] = o.continued_weight[1] = o.continued_weight[2] = 1.f;
@@ -766,6 +807,7 @@ __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp
         }
         o.aniso[0] = aniso.x; o.aniso[1] = aniso.y; o.aniso[2] = aniso.z;
         if (lane == 0) { outs[idx] = o; st->sampler_state = s.state; }
+        FS_T(10);
     }
 }
 

@@ -101,6 +101,8 @@ struct gpis_medium {
     FastTable fast;          // single-realization wave-cooperative path (gpis_fast.hpp); enabled == 0 when unused
     GuideField guide;        // certified guide field (gpis_guide.hpp); enabled == 0 until gpis_build_guide
     unsigned long long *d_guide_cnt;
+    void *fs_ws = nullptr;            // function-space workspace: one FsGlob per resident workgroup (gpis_fs.hpp)
+    unsigned fs_ws_blocks = 0;
     // staging for the *_host entries and workspace for the renderer (grown on demand)
     void *stage[5];
     size_t stage_bytes[5];
@@ -1254,6 +1256,7 @@ extern "C" int gpis_destroy(gpis_medium *m)
     fast_table_free(&m->fast);
     guide_free(&m->guide);
     if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
+    if (m->fs_ws) (void)hipFree(m->fs_ws);
     for (int k = 0; k < 2; ++k)
         for (auto &ev : m->events[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int i = 0; i < 5; ++i)
@@ -1686,12 +1689,28 @@ template <bool WANT_SAMPLE>
 static int fs_launch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, uint8_t *visible, hipStream_t s)
 {
     HIP_TRY(hipSetDevice(m->device));
-    // the workspace takes the LDS of a whole CU: one wave per CU is resident, a few per CU are queued
-    const size_t cap = (size_t)(m->n_cus > 0 ? m->n_cus : 256) * 4;
+    // 37 KB of LDS per workgroup: four one-wave workgroups (one per SIMD) are resident per CU and walk the batch
+    const unsigned cap = (unsigned)(m->n_cus > 0 ? m->n_cus : 256) * 4u;
+    {
+        std::lock_guard<std::mutex> lock(m->mu);
+        if (m->fs_ws_blocks < cap) {
+            if (m->fs_ws) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(m->fs_ws); m->fs_ws = nullptr; m->fs_ws_blocks = 0; }
+            if (hipMalloc(&m->fs_ws, (size_t)cap * sizeof(FsGlob)) != hipSuccess) { (void)hipGetLastError(); return set_err(GPIS_ERR_DEVICE, "function-space workspace allocation failed"); }
+            m->fs_ws_blocks = cap;
+        }
+    }
     const unsigned grid = (unsigned)(n < cap ? n : cap);
-    k_fs_march<WANT_SAMPLE><<<grid, 64, 0, s>>>(m->d_model, n, rays, states, out, visible);
+    k_fs_march<WANT_SAMPLE><<<grid, 64, 0, s>>>(m->d_model, n, rays, states, out, visible, (FsGlob *)m->fs_ws);
     return launch_check("k_fs_march");
 }
+#ifdef GPIS_FS_PROF
+extern "C" int gpis_fs_prof_read(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpis::g_fs_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return GPIS_ERR_DEVICE;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gpis::g_fs_prof), z, sizeof z) != hipSuccess) return GPIS_ERR_DEVICE; }
+    return GPIS_OK;
+}
+#endif
 extern "C" int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && states && out)));

@@ -73,7 +73,7 @@ def main():
         "gpu_first_segments_per_s": n / dt1, "gpu_conditioned_segments_per_s": n / dt2,
         "hit_fraction_first": float((out1["exited"] == 0).mean()), "ok_fraction_second": float((out2["ok"] == 1).mean()),
         "cpu_port": {"cores": os.cpu_count(), "sample": m, "first_segments_per_s": m / c1, "conditioned_segments_per_s": m / c2},
-        "kernel": "k_fs_march (one wave per segment, 146 KB LDS workspace, fp64)"}))
+        "kernel": "k_fs_march (one wave per segment, four segments per CU: 37 KB LDS + 104 KB L2-resident workspace each, fp64)"}))
 
 
 if __name__ == "__main__":
