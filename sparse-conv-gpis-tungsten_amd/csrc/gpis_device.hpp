@@ -416,9 +416,12 @@ struct FastLds {
     float4 xyr[64];                     // (x, y, kernelRadius * x, kernelRadius * y)
     float4 zw[64];                      // (z, kernelRadius * z, w = +-1, unused)
 #endif
+    // staging area of the sideways evaluators' ordered sums (ChainSum below): groups of four fp32 values, read back as broadcasts
+    float4 chain[64];
     // lane tables of the two-way candidate split (coop_noise3d): the r-th lane with a query / the r-th lane without one
     uint32_t owner_tab[64], idle_tab[64];
 };
+constexpr int kChainGroups = 64;
 template <class LDS>
 GPIS_DEV void fast_lds_init(LDS &lds)
 {
@@ -433,6 +436,56 @@ GPIS_DEV int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 GPIS_DEV float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 // lane k's value, k wave-uniform (v_readlane_b32: no LDS round trip)
 GPIS_DEV float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
+// ---- ordered sums of the sideways evaluators (lane = impulse) ------------------------------------------------
+// The reference adds the passing impulses of a cell in ascending k, starting from 0, and then adds the cell's sum to the
+// running sum, cells in dx,dy,dz order (SCN.cpp:368-371, 380-392).  With lane = impulse that is a serial chain over
+// values held by different lanes.  Round 1 walked the ballot with one v_readlane + v_add_f32 per value (9 issue
+// cycles; 11 % of the guided sampleDistance kernel's issue cycles).  Here the passing lanes' values are compacted
+// into LDS (slot = popcount of the ballot below the lane), padded with +0 to a multiple of four, and every lane sums
+// them from wave-uniform ds_read_b128 reads (a broadcast on the LDS pipe): 2 issue cycles per value.  The padding is
+// exact: x + (+0) = x for every x except -0, and a partial sum is never -0 (it starts from +0, and (+0) + (-0) = +0).
+struct ChainSum {
+    float sum = 0.f;                  // cells finished so far, in order
+    int used = 0;                     // groups staged (wave-uniform)
+    unsigned long long ends = 0ULL;   // bit g: group g closes its cell
+};
+template <class LDS>
+GPIS_DEV void chain_flush(LDS &lds, ChainSum &cs)
+{
+    // one wave per workgroup and in-order LDS: only the compiler has to be told that lanes talk to each other here
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float cell = 0.f;
+    for (int g = 0; g < cs.used; ++g) {
+        const float4 v = lds.chain[g];
+        cell = (((cell + v.x) + v.y) + v.z) + v.w;
+        if ((cs.ends >> g) & 1ULL) {
+            cs.sum = cs.sum + cell;
+            cell = 0.f;
+        }
+    }
+    cs.used = 0;
+    cs.ends = 0ULL;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// stages one cell: m = ballot of the lanes whose impulse passes (m != 0, wave-uniform), pass = this lane's bit, c = its value
+template <class LDS>
+GPIS_DEV void chain_push(LDS &lds, ChainSum &cs, unsigned long long m, bool pass, float c)
+{
+    const int cnt = __popcll(m), groups = (cnt + 3) >> 2;
+    if (cs.used + groups > kChainGroups)
+        chain_flush(lds, cs);
+    const int lane = (int)(threadIdx.x & 63);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    // passing lanes take slots 0 .. cnt-1 in lane order, the others follow (a permutation of 0 .. 63): they supply the +0 padding
+    const int slot = pass ? rank : cnt + (lane - rank);
+    if (slot < 4 * groups)
+        reinterpret_cast<float *>(lds.chain)[4 * cs.used + slot] = pass ? c : 0.f;
+    cs.used += groups;
+    cs.ends |= 1ULL << (cs.used - 1);
+}
 
 // expf_glibc with the table in LDS and the range checks folded into selects (same results).
 // NONPOS: the caller guarantees x <= 0 (or NaN), so the overflow check cannot fire and is left out.

@@ -383,8 +383,9 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
 
 // noise3D VALUE for ONE query (the one held by lane `src`, src wave-uniform) with the wave turned
 // sideways: lane k owns impulse k of the current cell and evaluates its kernel against the single query
-// point; the cell sum is then accumulated over the passing lanes in ascending k (a v_readlane chain),
-// which is the reference's order (SCN.cpp:383-392), and cells in dx,dy,dz order (SCN.cpp:368-371).
+// point; the cell sum is then accumulated over the passing lanes in ascending k (ChainSum: compacted into LDS
+// and read back as broadcasts), which is the reference's order (SCN.cpp:383-392), and cells in dx,dy,dz order
+// (SCN.cpp:368-371).
 // ~2.4k instructions per query against ~10k for a cooperative evaluation: used when only a few lanes
 // of a wave need an exact value.  The result is wave-uniform.
 GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds &lds, int src, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
@@ -407,7 +408,7 @@ GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds
     const uint32_t n = M.n_impulses;
     const int H = T.half, S = T.stride;
     const unsigned side = 2u * (unsigned)H;
-    float sum = 0.f;
+    ChainSum cs;
     for (int di = -1; di <= 1; ++di)
         for (int dj = -1; dj <= 1; ++dj)
             for (int dk = -1; dk <= 1; ++dk) {
@@ -422,22 +423,17 @@ GPIS_DEV float solo_noise3d_value(const DevModel &M, const FastTable &T, FastLds
                 }
                 const V3 pc = v3(fx, fy, fz) - v3((float)di, (float)dj, (float)dk);
                 const bool pass = (uint32_t)lane < n && length_sq(pc - v3(px, py, pz)) < 1.0f;
-                unsigned long long m = __ballot(pass);
+                const unsigned long long m = __ballot(pass);
                 if (m == 0ULL)
                     continue;
                 const V3 ab = R * pc - R * v3(px, py, pz);
                 const V3 t = v3(ab.x * A0, ab.y * A1, ab.z * A2);
                 const float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
                 const float c = pw * expf_glibc_lds<true>(lds, -absq);      // absq >= 0: no overflow check
-                float cell = 0.f;
-                while (m) {
-                    const int k = __builtin_ctzll(m);
-                    m &= m - 1ULL;
-                    cell = cell + lane_f(c, k);
-                }
-                sum = sum + cell;
+                chain_push(lds, cs, m, pass, c);
             }
-    return sum;
+    chain_flush(lds, cs);
+    return cs.sum;
 }
 
 // The same evaluation with 64 / S cells per pass (two at rho <= 32): lane = (cell of the pass, impulse).
@@ -467,7 +463,7 @@ GPIS_DEV float solo_noise3d_value_packed(const DevModel &M, const FastTable &T, 
     const int per_pass = 64 / S;
     const int sub = lane / S, k_imp = lane & (S - 1);
     const unsigned long long cell_bits = S == 64 ? ~0ULL : ((1ULL << S) - 1ULL);
-    float sum = 0.f;
+    ChainSum cs;
     for (int c0 = 0; c0 < 27; c0 += per_pass) {
         const int c = c0 + sub;
         const int di = c / 9 - 1, dj = (c / 3) % 3 - 1, dk = c % 3 - 1;      // dx, dy, dz order (SCN.cpp:368-371)
@@ -493,19 +489,14 @@ GPIS_DEV float solo_noise3d_value_packed(const DevModel &M, const FastTable &T, 
         const float absq = sum3e(t.x * ab.x, t.y * ab.y, t.z * ab.z);
         const float cv = pw * expf_glibc_lds<true>(lds, -absq);     // absq >= 0: no overflow check
         for (int g = 0; g < per_pass; ++g) {
-            unsigned long long mg = (m >> (g * S)) & cell_bits;
+            const unsigned long long mg = m & (cell_bits << (g * S));
             if (mg == 0ULL)
                 continue;                      // an empty cell adds +0: exact to skip
-            float cell = 0.f;
-            while (mg) {
-                const int k = __builtin_ctzll(mg);
-                mg &= mg - 1ULL;
-                cell = cell + lane_f(cv, k + g * S);
-            }
-            sum = sum + cell;
+            chain_push(lds, cs, mg, pass && sub == g, cv);
         }
     }
-    return sum;
+    chain_flush(lds, cs);
+    return cs.sum;
 }
 
 // evaluateNoise3D for the stationary single-realization case (SCN.cpp:101-116, 251-260, 291-320):
