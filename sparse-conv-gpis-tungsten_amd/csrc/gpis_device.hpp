@@ -456,14 +456,16 @@ GPIS_DEV void chain_flush(LDS &lds, ChainSum &cs)
     // one wave per workgroup and in-order LDS: only the compiler has to be told that lanes talk to each other here
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    float cell = 0.f;
-    for (int g = 0; g < cs.used; ++g) {
-        const float4 v = lds.chain[g];
-        cell = (((cell + v.x) + v.y) + v.z) + v.w;
-        if ((cs.ends >> g) & 1ULL) {
-            cs.sum = cs.sum + cell;
-            cell = 0.f;
+    // scalar control flow throughout: `ends` and the group index live in SGPRs
+    int g = 0;
+    for (unsigned long long e = cs.ends; e; e &= e - 1ULL) {
+        const int last = __builtin_ctzll(e);
+        float cell = 0.f;
+        for (; g <= last; ++g) {
+            const float4 v = lds.chain[g];
+            cell = (((cell + v.x) + v.y) + v.z) + v.w;
         }
+        cs.sum = cs.sum + cell;
     }
     cs.used = 0;
     cs.ends = 0ULL;
@@ -475,7 +477,7 @@ template <class LDS>
 GPIS_DEV void chain_push(LDS &lds, ChainSum &cs, unsigned long long m, bool pass, float c)
 {
     const int cnt = __popcll(m), groups = (cnt + 3) >> 2;
-    if (cs.used + groups > kChainGroups)
+    if (__builtin_expect(cs.used + groups > kChainGroups, 0))
         chain_flush(lds, cs);
     const int lane = (int)(threadIdx.x & 63);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -176,29 +176,36 @@ GPIS_DEV bool guide_lookup(const GuideField &F, V3 u, float &g, float &err)
 
 GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err)
 {
+    typedef const float __attribute__((address_space(1))) *gfloat_p;   // the field is read through a struct in memory: keep the loads global_load
     const float fx0 = floorf(tx), fy0 = floorf(ty), fz0 = floorf(tz);
-    const float lim = (float)(F.side - 2);
-    if (!(fx0 >= 0.f && fy0 >= 0.f && fz0 >= 0.f && fx0 <= lim && fy0 <= lim && fz0 <= lim))
+    // v_cvt_i32_f32 saturates and maps NaN to 0 (then the weights are NaN and no sign is certified), so one unsigned compare per
+    // axis is the whole range check
+    const uint32_t ix = (uint32_t)(int)fx0, iy = (uint32_t)(int)fy0, iz = (uint32_t)(int)fz0;
+    const uint32_t side = (uint32_t)F.side, lim = side - 2u;
+    if (!(ix <= lim && iy <= lim && iz <= lim))
         return false;
-    const int ix = (int)fx0, iy = (int)fy0, iz = (int)fz0;
     const float wx = tx - fx0, wy = ty - fy0, wz = tz - fz0;
-    const size_t side = (size_t)F.side;
-    const float *p00 = F.G + ((size_t)ix * side + (size_t)iy) * side + (size_t)iz;
-    const float *p01 = p00 + side, *p10 = p00 + side * side, *p11 = p10 + side;
+    // side <= 8192 (guide_build): ix*side + iy < 2^26 is a 24-bit multiply-add, the element index one 32x32->64 multiply-add
+    // (as size_t arithmetic on ints this was 30 instructions of sign extensions and 64x64 multiplies per march step)
+    const uint32_t row = __umul24(ix, side) + iy;
+    gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)row * side + iz);
+    gfloat_p p01 = p00 + side, p10 = p00 + (size_t)side * side, p11 = p10 + side;
     const float a000 = p00[0], a001 = p00[1], a010 = p01[0], a011 = p01[1];
     const float a100 = p10[0], a101 = p10[1], a110 = p11[0], a111 = p11[1];
-    const float c00 = a000 + (a001 - a000) * wz, c01 = a010 + (a011 - a010) * wz;
-    const float c10 = a100 + (a101 - a100) * wz, c11 = a110 + (a111 - a110) * wz;
-    const float c0 = c00 + (c01 - c00) * wy, c1 = c10 + (c11 - c10) * wy;
-    g = c0 + (c1 - c0) * wx;
-    const size_t bs = side / 4;
-    err = F.err[((size_t)(ix >> 2) * bs + (size_t)(iy >> 2)) * bs + (size_t)(iz >> 2)];
+    // fused lerps: the guide value is not part of any result, its rounding is inside the stored bound's 5e-4 + 1e-3 relative
+    const float c00 = __builtin_fmaf(a001 - a000, wz, a000), c01 = __builtin_fmaf(a011 - a010, wz, a010);
+    const float c10 = __builtin_fmaf(a101 - a100, wz, a100), c11 = __builtin_fmaf(a111 - a110, wz, a110);
+    const float c0 = __builtin_fmaf(c01 - c00, wy, c00), c1 = __builtin_fmaf(c11 - c10, wy, c10);
+    g = __builtin_fmaf(c1 - c0, wx, c0);
+    const uint32_t bs = side >> 2;
+    const uint32_t brow = __umul24(ix >> 2, bs) + (iy >> 2);
+    err = ((gfloat_p)F.err)[(uint64_t)brow * bs + (iz >> 2)];
     return true;
 }
 
-// fp32 mean for the certification (the exact path evaluates it in double, GPF.hpp:903-945);
-// `slack` returns a bound on its absolute error
-GPIS_DEV float mean_approx(const DevModel &M, V3 p, float &slack)
+// fp32 mean for the certification (the exact path evaluates it in double, GPF.hpp:903-945); `slack` returns a bound on
+// its absolute error.  `perr` bounds the 1-norm distance between p and the position the exact evaluator uses.
+GPIS_DEV float mean_approx(const DevModel &M, V3 p, float perr, float &slack)
 {
     float best = 0.f;
     slack = 0.f;
@@ -209,14 +216,17 @@ GPIS_DEV float mean_approx(const DevModel &M, V3 p, float &slack)
             v = mu.offset; s = 0.f;
         } else if (mu.type == GPIS_MEAN_SPHERICAL) {
             const float dx = p.x - (float)mu.center[0], dy = p.y - (float)mu.center[1], dz = p.z - (float)mu.center[2];
-            const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+            // v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf (16 instructions): its error is inside the 6e-7 r term
+            const float r = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
             v = r - mu.radius;
-            s = 4e-7f * (r + fabsf((float)mu.center[0]) + fabsf((float)mu.center[1]) + fabsf((float)mu.center[2]) + fabsf(mu.radius)) + 1e-7f;
+            s = 6e-7f * (r + fabsf((float)mu.center[0]) + fabsf((float)mu.center[1]) + fabsf((float)mu.center[2]) + fabsf(mu.radius)) + 1e-7f + perr;   // |r(p) - r(p')| <= |p - p'|
         } else {
             const float dx = p.x - (float)mu.center[0], dy = p.y - (float)mu.center[1], dz = p.z - (float)mu.center[2];
-            const float d = dx * (float)M.lin_dir[w][0] + dy * (float)M.lin_dir[w][1] + dz * (float)M.lin_dir[w][2];
+            const float l0 = (float)M.lin_dir[w][0], l1 = (float)M.lin_dir[w][1], l2 = (float)M.lin_dir[w][2];
+            const float d = dx * l0 + dy * l1 + dz * l2;
             v = fmaxf(d * mu.scale, mu.min);
-            s = 1e-6f * (fabsf(d * mu.scale) + fabsf(mu.scale) * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + 1.f)) + 1e-7f;
+            s = 1e-6f * (fabsf(d * mu.scale) + fabsf(mu.scale) * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + 1.f)) + 1e-7f
+                + 1.001f * fabsf(mu.scale) * fmaxf(fabsf(l0), fmaxf(fabsf(l1), fabsf(l2))) * perr;
         }
         if (w == 0 || v < best) best = v;          // CSG min (GaussianProcess.cpp:379-393): |min(a,b) - min(a',b')| <= max err
         slack = fmaxf(slack, s);
@@ -252,7 +262,7 @@ GPIS_DEV int guide_sign(const DevModel &M, const GuideField &F, V3 p, const Fram
         return 0;
     const float norm = M.iso3d ? M.norm3d_iso : M.norm3d_world;
     float ms;
-    const float mean = mean_approx(M, p, ms);
+    const float mean = mean_approx(M, p, 0.f, ms);
     const float nv = M.sigma * (g / norm);
     const float fa = nv + mean;
     const float margin = M.sigma * (err / norm) * 1.0001f + ms + 2e-6f * (fabsf(nv) + fabsf(mean)) + 1e-7f;
@@ -261,13 +271,20 @@ GPIS_DEV int guide_sign(const DevModel &M, const GuideField &F, V3 p, const Fram
     return 0;
 }
 
-// The march visits p(t) = pos + t*dir, and the grid position is a LINEAR map of p (iso-ray space:
-// rotation into the ray frame of the whitened position; world space: p / R), so the index-space
-// coordinates of a step are a + t*b with a, b computed once per segment in double.  The lookup position
-// then differs from the fp32 position the exact evaluator derives for the same t by a few fp32 ulps of
-// |u| <= half (< 2e-5 cells), inside the 1e-4 position slack the stored bound carries (k_guide_build).
+// The march visits p(t) = pos + t*dir, and the grid position is a LINEAR map of p (iso-ray space: rotation into the
+// ray frame of the whitened position; world space: p / R), so the index-space coordinates of a step are a + t*b with
+// a, b computed once per segment in double and kept in fp32; a step evaluates them with one fp32 fma each.
+// Error of the lookup position against the position u the exact evaluator derives for the same t (the stored bound
+// carries kGuidePosEps = 1e-4 cells for it, k_guide_build): the roundings of a, b, (float)t and of the fma are each
+// <= 2^-24 of an index coordinate <= side, i.e. <= 4 x 2 half x 6e-8 cells = 3e-5 cells at half = 64 (8e-6 at 16); u itself
+// is a chain of ~8 fp32 roundings of |u| <= half cells (measured < 2e-5 at half = 16).  gpis_guide_raycheck walks real
+// rays and checks every certified sign against the exact value.
+// The mean is evaluated at pos + (float)t * dir in fp32; `pe0 + pe1 |t|` bounds its 1-norm distance from the exact
+// evaluator's float(pos_d + t dir_d): (|t - (float)t| |dir_c| + two roundings of |p_c|) summed over the components.
 struct GuideRay {
-    double ax, ay, az, bx, by, bz;   // index coordinates = a + t*b
+    float ax, ay, az, bx, by, bz;    // index coordinates = a + t*b
+    V3 pos, dir;                     // the ray (world space)
+    float pe0, pe1;                  // position slack = pe0 + pe1 * |t|
     float sn;                        // sigma / norm
 };
 
@@ -287,23 +304,31 @@ GPIS_DEV GuideRay guide_ray(const DevModel &M, const GuideField &F, V3 pos, V3 d
         const double s = (double)F.ppc / (double)F.R;
         x = wx * s; y = wy * s; z = wz * s;
     };
-    GuideRay g;
-    lin(pos, g.ax, g.ay, g.az);
-    lin(dir, g.bx, g.by, g.bz);
+    double ax, ay, az, bx, by, bz;
+    lin(pos, ax, ay, az);
+    lin(dir, bx, by, bz);
     const double off = (double)F.half * (double)F.ppc;
-    g.ax += off; g.ay += off; g.az += off;
+    GuideRay g;
+    g.ax = (float)(ax + off); g.ay = (float)(ay + off); g.az = (float)(az + off);
+    g.bx = (float)bx; g.by = (float)by; g.bz = (float)bz;
+    g.pos = pos; g.dir = dir;
+    const float d1 = fabsf(dir.x) + fabsf(dir.y) + fabsf(dir.z);
+    g.pe0 = 2.5e-7f * (fabsf(pos.x) + fabsf(pos.y) + fabsf(pos.z));
+    g.pe1 = 2.5e-7f * d1;
     g.sn = M.sigma / (M.iso3d ? M.norm3d_iso : M.norm3d_world);
     return g;
 }
 
-// certified sign at march parameter t (world point p = pos + t*dir): +1 / -1, or 0 when undecided
-GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRay &gr, double t, V3 p)
+// certified sign at march parameter t (world point pos + t*dir): +1 / -1, or 0 when undecided
+GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRay &gr, double t)
 {
+    const float tf = (float)t;
     float g, err;
-    if (!guide_lookup_index(F, (float)(gr.ax + t * gr.bx), (float)(gr.ay + t * gr.by), (float)(gr.az + t * gr.bz), g, err))
+    if (!guide_lookup_index(F, __builtin_fmaf(tf, gr.bx, gr.ax), __builtin_fmaf(tf, gr.by, gr.ay), __builtin_fmaf(tf, gr.bz, gr.az), g, err))
         return 0;
+    const V3 p = v3(__builtin_fmaf(tf, gr.dir.x, gr.pos.x), __builtin_fmaf(tf, gr.dir.y, gr.pos.y), __builtin_fmaf(tf, gr.dir.z, gr.pos.z));
     float ms;
-    const float mean = mean_approx(M, p, ms);
+    const float mean = mean_approx(M, p, __builtin_fmaf(fabsf(tf), gr.pe1, gr.pe0), ms);
     const float nv = g * gr.sn;
     const float fa = nv + mean;
     // 4e-6 relative also covers sigma*(g/norm) vs g*(sigma/norm) and the product roundings
@@ -430,7 +455,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
             FSTAT(21, __popcll(step_mask));
             if (stepping) {
                 if (phase == G_INIT) {
-                    const int s = guide_sign_at(M, F, gr, (double)nearT, world_at((double)nearT));
+                    const int s = guide_sign_at(M, F, gr, (double)nearT);
                     if (s != 0) {
                         n_guide++;          // counts certified steps: each stands for one evaluateValue of the reference
                         sign0 = s;
@@ -440,7 +465,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
                         phase = X_F0;
                     }
                 } else {
-                    const int s = guide_sign_at(M, F, gr, t, world_at(t));
+                    const int s = guide_sign_at(M, F, gr, t);
                     const bool adopt = !first_scatter && step == 0;   // the reference's `step == 1` after step++ (SCNM.cpp:138-140)
                     if (s != 0 && (adopt || s == sign0)) {
                         n_guide++;
@@ -576,7 +601,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
 struct GuideCounters { unsigned long long n_guide; };
 
 template <bool SMALLARG>
-__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_distance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_distance(const DevModel *__restrict__ Mp, FastTable T, const GuideField *__restrict__ Fp, size_t n,
                                                                                      const gpis_ray_in *__restrict__ rays, gpis_seg_out *__restrict__ out,
                                                                                      gpis_cond_coeff *__restrict__ coeff, const uint8_t *__restrict__ mask,
                                                                                      Counters *cnt, unsigned long long *guide_cnt)
@@ -587,7 +612,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_di
     const bool valid = i < n && (!mask || mask[i]);
     uint32_t n_eval = 0, n_guide = 0;
     bool vis;
-    guided_march<true, SMALLARG>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval, n_guide);
+    guided_march<true, SMALLARG>(*Mp, T, *Fp, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval, n_guide);
     if (valid && coeff) {
         gpis_cond_coeff c;
         memset(&c, 0, sizeof c);
@@ -601,7 +626,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_di
 }
 
 template <bool SMALLARG>
-__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC_TR) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC_TR) k_guided_transmittance(const DevModel *__restrict__ Mp, FastTable T, const GuideField *__restrict__ Fp, size_t n,
                                                                                    const gpis_ray_in *__restrict__ rays, uint8_t *__restrict__ visible,
                                                                                    const uint8_t *__restrict__ mask, Counters *cnt, unsigned long long *guide_cnt)
 {
@@ -611,7 +636,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC_TR) k_guided_transm
     const bool valid = i < n && (!mask || mask[i]);
     uint32_t n_eval = 0, n_guide = 0;
     bool vis = false;
-    guided_march<false, SMALLARG>(*Mp, T, F, lds, valid, rays + (valid ? i : 0), nullptr, vis, n_eval, n_guide);
+    guided_march<false, SMALLARG>(*Mp, T, *Fp, lds, valid, rays + (valid ? i : 0), nullptr, vis, n_eval, n_guide);
     if (i < n)
         visible[i] = (valid && vis) ? 1 : 0;
     fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
@@ -697,7 +722,7 @@ __global__ void __launch_bounds__(kFastBlock) k_guide_raycheck(const DevModel *_
     for (uint32_t k = 0; k < steps; ++k) {
         const bool live = valid && t < (double)farT;
         const V3 p = to_f(ray_at(to_d(pos), to_d(dir), t));
-        const int s = live ? guide_sign_at(M, F, gr, t, p) : 0;
+        const int s = live ? guide_sign_at(M, F, gr, t) : 0;
         // exact values for the lanes that hold a certificate, clustered like the march does
         bool pending = s != 0;
         const V3 ug = grid_point(M, F, p, coord);

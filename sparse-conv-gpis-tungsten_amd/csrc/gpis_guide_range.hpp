@@ -205,7 +205,7 @@ GPIS_DEV void guided_march_range(const DevModel &M, const FastTable &T, const Gu
                 break;
             if (stepping) {
                 if (phase == G_INIT) {
-                    const int s = guide_sign_at(M, F, gr, (double)nearT, world_at((double)nearT));
+                    const int s = guide_sign_at(M, F, gr, (double)nearT);
                     if (s != 0) {
                         n_guide++;
                         sign0 = s;
@@ -215,7 +215,7 @@ GPIS_DEV void guided_march_range(const DevModel &M, const FastTable &T, const Gu
                         phase = X_F0;
                     }
                 } else {
-                    const int s = guide_sign_at(M, F, gr, t, world_at(t));
+                    const int s = guide_sign_at(M, F, gr, t);
                     const bool adopt = !first_scatter && step == 0;
                     if (s != 0 && (adopt || s == sign0)) {
                         n_guide++;

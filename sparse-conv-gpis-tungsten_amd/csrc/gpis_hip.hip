@@ -101,6 +101,7 @@ struct gpis_medium {
     FastTable fast;          // single-realization wave-cooperative path (gpis_fast.hpp); enabled == 0 when unused
     GuideField guide;        // certified guide field (gpis_guide.hpp); enabled == 0 until gpis_build_guide
     unsigned long long *d_guide_cnt;
+    GuideField *d_guide;     // device copy of `guide` (the resident guided kernels read it through scalar loads instead of 14 kernel-argument SGPRs)
     void *fs_ws = nullptr;            // function-space workspace: one FsGlob per resident workgroup (gpis_fs.hpp)
     unsigned fs_ws_blocks = 0;
     // staging for the *_host entries and workspace for the renderer (grown on demand)
@@ -1188,7 +1189,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     m->params = *params;
     m->device = device;
     for (int i = 0; i < 5; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
-    m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr;
+    m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr; m->d_guide = nullptr;
     m->batch_hint = GPIS_ORDER_COHERENT;
     for (int k = 0; k < 2; ++k) { m->ws_event[k] = nullptr; m->ws_event_set[k] = false; }
     memset(m->hs, 0, sizeof m->hs);
@@ -1224,6 +1225,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     if (e == hipSuccess) e = hipMalloc(&m->d_counters, 2 * sizeof(Counters));
     if (e == hipSuccess) e = hipMalloc(&m->d_guide_cnt, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(m->d_guide_cnt, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&m->d_guide, sizeof(GuideField));
+    if (e == hipSuccess) e = hipMemset(m->d_guide, 0, sizeof(GuideField));
     if (e == hipSuccess) e = hipMalloc(&m->d_next, kPersistSlots * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemcpy(m->d_model, &m->host_model, sizeof(DevModel), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(m->d_counters, 0, 2 * sizeof(Counters));
@@ -1232,6 +1235,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         if (m->d_model) (void)hipFree(m->d_model);
         if (m->d_counters) (void)hipFree(m->d_counters);
         if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
+        if (m->d_guide) (void)hipFree(m->d_guide);
         if (m->d_next) (void)hipFree(m->d_next);
         delete m;
         return GPIS_ERR_DEVICE;
@@ -1239,7 +1243,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     st = fast_table_build(m->host_model, m->d_model, &m->fast);
     if (st != GPIS_OK) {
         set_err(st, "gpis_create: building the cell table failed");
-        (void)hipFree(m->d_model); (void)hipFree(m->d_counters); (void)hipFree(m->d_guide_cnt); (void)hipFree(m->d_next);
+        (void)hipFree(m->d_model); (void)hipFree(m->d_counters); (void)hipFree(m->d_guide_cnt); (void)hipFree(m->d_guide); (void)hipFree(m->d_next);
         delete m;
         return st;
     }
@@ -1256,6 +1260,7 @@ extern "C" int gpis_destroy(gpis_medium *m)
     fast_table_free(&m->fast);
     guide_free(&m->guide);
     if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
+    if (m->d_guide) (void)hipFree(m->d_guide);
     if (m->fs_ws) (void)hipFree(m->fs_ws);
     for (int k = 0; k < 2; ++k)
         for (auto &ev : m->events[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -1509,9 +1514,9 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
     }
     if (m->guide.enabled) {
         if (m->host_model.exp_arg_max < 100.f)
-            k_guided_sample_distance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
+            k_guided_sample_distance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
         else
-            k_guided_sample_distance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
+            k_guided_sample_distance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
         return launch_check("k_guided_sample_distance");
     }
     if (m->fast.enabled) {
@@ -1555,9 +1560,9 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
     }
     if (m->guide.enabled) {
         if (m->host_model.exp_arg_max < 100.f)
-            k_guided_transmittance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
+            k_guided_transmittance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
         else
-            k_guided_transmittance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
+            k_guided_transmittance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
         return launch_check("k_guided_transmittance");
     }
     if (m->fast.enabled) {
@@ -1980,6 +1985,7 @@ extern "C" int gpis_build_guide(gpis_medium *m, int half_extent_cells, int point
     if (st != GPIS_OK)
         return set_err(st, "gpis_build_guide(half=%d, ppc=%d) failed: %s", half_extent_cells, points_per_cell,
                        st == GPIS_ERR_UNSUPPORTED ? "unsupported arguments" : hipGetErrorString(hipGetLastError()));
+    HIP_TRY(hipMemcpy(m->d_guide, &m->guide, sizeof(GuideField), hipMemcpyHostToDevice));
     return GPIS_OK;
 }
 extern "C" int gpis_drop_guide(gpis_medium *m)
@@ -1989,6 +1995,7 @@ extern "C" int gpis_drop_guide(gpis_medium *m)
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipDeviceSynchronize());
     guide_free(&m->guide);
+    HIP_TRY(hipMemcpy(m->d_guide, &m->guide, sizeof(GuideField), hipMemcpyHostToDevice));
     return GPIS_OK;
 }
 extern "C" int gpis_get_guide_steps(gpis_medium *m, uint64_t *n_guide)

@@ -193,7 +193,7 @@ GPIS_DEV void wave_guide_steps(const DevModel &M, const GuideField &F, const Wav
             s.phase = G_DONE;
         }
         if (s.phase == G_INIT) {
-            const int sg = guide_sign_at(M, F, gr, (double)w.nearT, wave_point(w, (double)w.nearT));
+            const int sg = guide_sign_at(M, F, gr, (double)w.nearT);
             if (sg != 0) {
                 n_guide++;
                 s.sign0 = (int8_t)sg;
@@ -203,7 +203,7 @@ GPIS_DEV void wave_guide_steps(const DevModel &M, const GuideField &F, const Wav
                 s.phase = X_F0;
             }
         } else if (s.phase == G_MARCH) {
-            const int sg = guide_sign_at(M, F, gr, s.t, wave_point(w, s.t));
+            const int sg = guide_sign_at(M, F, gr, s.t);
             const bool adopt = !w.first_scatter && s.step == 0;   // SCNM.cpp:138-140
             if (sg != 0 && (adopt || sg == s.sign0)) {
                 n_guide++;
