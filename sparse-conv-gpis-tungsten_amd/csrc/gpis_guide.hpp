@@ -68,6 +68,10 @@ struct GuideField {
 #ifndef GPIS_GUIDE_SPLIT
 #define GPIS_GUIDE_SPLIT 1
 #endif
+#ifndef GPIS_SOLO_PACKED
+#define GPIS_SOLO_PACKED 0
+#endif
+constexpr bool kSoloPacked = GPIS_SOLO_PACKED != 0;   // sideways evaluator with 64 / stride cells per pass (measured slower in the resident kernels: C1 403 vs 412 Msamples/s)
 constexpr bool kGuideSplit = GPIS_GUIDE_SPLIT != 0;   // two-way candidate split for clusters of at most 32 lanes
 constexpr int kSoloMaxLanes = GPIS_SOLO_MAX;   // clusters up to this size use the sideways evaluator
 constexpr float kGuidePosEps = 1e-4f;         // bound on |u - w| per axis (cells): measured < 2e-5, see GuideRay
@@ -509,7 +513,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
             for (unsigned long long mm = cl_mask; mm; mm &= mm - 1ULL) {
                 const int src = __builtin_ctzll(mm);
                 int gpx;
-                const float v = solo_evaluate_value(M, T, lds, src, pq, coord, gpx, n_eval);
+                const float v = solo_evaluate_value<kSoloPacked>(M, T, lds, src, pq, coord, gpx, n_eval);
                 if ((int)(threadIdx.x & 63) == src) { fv = v; gp_new = gpx; }
             }
         } else {

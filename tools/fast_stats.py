@@ -13,7 +13,7 @@ if os.path.exists(prebuilt):
     so = prebuilt
 else:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                           "-DGPIS_FAST_STATS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so, os.path.join(csrc, "gpis_hip.hip")])
+                           "-DGPIS_FAST_STATS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so, os.path.join(csrc, "gpis_hip.hip"), os.path.join(csrc, "gpis_sort.hip")])
 import torch
 lib = pkg.GpisLib(so)
 w, h, spp = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (480, 270, 64)))
