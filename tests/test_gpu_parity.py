@@ -162,6 +162,26 @@ def test_march_bit_exact(env, cfg, res, step, path):
     assert np.array_equal(to_host(d_o, pkg.SEG_OUT), got)
 
 
+@pytest.mark.parametrize("path", ["fast", "guided_coarse", "guided_fine_partial", "guided_wave"])
+def test_march_dense_cells(env, path):
+    """C1 at 64 impulses per cell (the densest medium the wave-cooperative path takes): 64-slot cell table, every lane of the
+    sideways evaluators owns an impulse, and one query has more passing impulses (~270) than the LDS staging area of the ordered sum
+    holds (256 values), so the sum is flushed in the middle of a query."""
+    pkg, ob, lib = env
+    params = pkg.params_for_config("C1")
+    params["impulse_density"] = 64
+    med, orc = _medium(pkg, params, path), ob.Oracle(params, threads=16)
+    scene = ob.default_scene_s(480, 270, 2)
+    rays, us = scene_rays(ob, orc, scene, step=11)
+    assert len(rays) > 300
+    got, want = med.sample_distance(rays), orc.sample_distance(rays)
+    for f in ("ok", "exited", "t", "aniso", "sample_t", "continued_t", "weight", "p", "last_val", "gp_id"):
+        assert np.array_equal(got[f], want[f]), f
+    assert (want["exited"] == 0).sum() > 50 and (want["exited"] == 1).sum() > 50
+    sh = shadow_rays_from(ob, scene, rays, us, want)
+    assert np.array_equal(med.transmittance(sh), orc.transmittance(sh))
+
+
 @pytest.mark.parametrize("path", PATHS)
 def test_march_edge_cases(env, path):
     pkg, ob, lib = env
