@@ -218,7 +218,7 @@ def main():
                          "slice of every pixel (weak scaling, N times the samples)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / sharding self-test over gloo on CPU: no GPU work, no metric")
     ap.add_argument("--guide", default="16:64", help="certified guide field 'half_extent_cells:points_per_cell' for "
-                    "single-realization media, or 'off' (built once before the timed region: 34 GB / 3.3 s at 16:64, "
+                    "single-realization media, or 'off' (built once before the timed region: 34 GB / 2 s at 16:64, "
                     "4.3 GB / 0.3 s at 16:32; falls back to 16:32 if the allocation fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unguided", action="store_true", help="skip the extra unguided frame (value_unguided)")
