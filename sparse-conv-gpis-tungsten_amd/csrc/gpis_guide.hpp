@@ -41,7 +41,7 @@ namespace gpis {
 
 struct GuideField {
     float *G;            // side^3 samples, z fastest
-    float *err;          // (side/4)^3 block bounds
+    float *err;          // (side/4)^3 blocks x 2: the bound Err of the block, and amax = a bound on |N| anywhere in the block's cells
     int half;            // extent in cells: u in [-half, half)
     int ppc;             // grid points per cell (h = 1/ppc)
     int side;            // 2*half*ppc
@@ -206,7 +206,32 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
     float emax = err;
     for (int off = 32; off > 0; off >>= 1) emax = fmaxf(emax, __shfl_xor(emax, off, 64));
     if (lane == 0)
-        F.err[((size_t)bx * bs + (size_t)by) * bs + (size_t)bz] = emax;
+        F.err[2 * (((size_t)bx * bs + (size_t)by) * bs + (size_t)bz)] = emax;
+}
+
+// Second pass of the build: amax(block) = max |V| over the corners of every cell anchored in the block (5x5x5 grid points: the last
+// layer belongs to the neighbouring blocks) + Err(block).  The interpolant of a cell is a convex combination of its corners, so
+// |N_ref(u)| <= |G(u)| + Err <= amax for every u the march can look up in the block: when the mean alone exceeds sigma amax / norm
+// the sign of the field is the sign of the mean, and the march skips the 8-tap lookup (guide_sign_at, level 0).
+__global__ void __launch_bounds__(256) k_guide_amax(GuideField F, size_t block_offset, size_t nblk)
+{
+    const size_t b = block_offset + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk)
+        return;
+    const int bs = F.side / 4;
+    const int bz = (int)(b % bs), by = (int)((b / bs) % bs), bx = (int)(b / ((size_t)bs * bs));
+    const int last = F.side - 1;
+    float m = 0.f;
+    for (int dx = 0; dx <= 4; ++dx) {
+        const int ix = min(4 * bx + dx, last);
+        for (int dy = 0; dy <= 4; ++dy) {
+            const int iy = min(4 * by + dy, last);
+            const float *row = F.G + ((size_t)ix * F.side + (size_t)iy) * F.side;
+            for (int dz = 0; dz <= 4; ++dz)
+                m = fmaxf(m, fabsf(row[min(4 * bz + dz, last)]));
+        }
+    }
+    F.err[2 * b + 1] = m + F.err[2 * b];
 }
 
 // G and the bound at index-space coordinates (tx, ty, tz) = (u + half) * ppc; false outside the
@@ -245,7 +270,7 @@ GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float 
     g = __builtin_fmaf(c1 - c0, wx, c0);
     const uint32_t bs = side >> 2;
     const uint32_t brow = __umul24(ix >> 2, bs) + (iy >> 2);
-    err = ((gfloat_p)F.err)[(uint64_t)brow * bs + (iz >> 2)];
+    err = ((gfloat_p)F.err)[2u * ((uint64_t)brow * bs + (iz >> 2))];
     return true;
 }
 
@@ -365,20 +390,45 @@ GPIS_DEV GuideRay guide_ray(const DevModel &M, const GuideField &F, V3 pos, V3 d
     return g;
 }
 
-// certified sign at march parameter t (world point pos + t*dir): +1 / -1, or 0 when undecided
+// certified sign at march parameter t (world point pos + t*dir): +1 / -1, or 0 when undecided.
+// Level 0: the block's bound on |N| against the mean (one 8-byte load); level 1: the trilinear lookup.  Far from the surface
+// — most steps of a march — level 0 decides.
 GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRay &gr, double t)
 {
+    typedef const float __attribute__((address_space(1))) *gfloat_p;
     const float tf = (float)t;
-    float g, err;
-    if (!guide_lookup_index(F, __builtin_fmaf(tf, gr.bx, gr.ax), __builtin_fmaf(tf, gr.by, gr.ay), __builtin_fmaf(tf, gr.bz, gr.az), g, err))
+    const float tx = __builtin_fmaf(tf, gr.bx, gr.ax), ty = __builtin_fmaf(tf, gr.by, gr.ay), tz = __builtin_fmaf(tf, gr.bz, gr.az);
+    const float fx0 = floorf(tx), fy0 = floorf(ty), fz0 = floorf(tz);
+    // v_cvt_i32_f32 saturates and maps NaN to 0 (then the comparisons below fail and no sign is certified)
+    const uint32_t ix = (uint32_t)(int)fx0, iy = (uint32_t)(int)fy0, iz = (uint32_t)(int)fz0;
+    const uint32_t side = (uint32_t)F.side, lim = side - 2u;
+    if (!(ix <= lim && iy <= lim && iz <= lim))
         return 0;
+    const uint32_t bs = side >> 2;
+    const uint32_t brow = __umul24(ix >> 2, bs) + (iy >> 2);
+    gfloat_p pe = (gfloat_p)__builtin_assume_aligned(F.err, 8) + 2u * ((uint64_t)brow * bs + (iz >> 2));
+    const float e_err = pe[0], e_amax = pe[1];                                   // (Err, amax) of the block: one 8-byte load
     const V3 p = v3(__builtin_fmaf(tf, gr.dir.x, gr.pos.x), __builtin_fmaf(tf, gr.dir.y, gr.pos.y), __builtin_fmaf(tf, gr.dir.z, gr.pos.z));
     float ms;
     const float mean = mean_approx(M, p, __builtin_fmaf(fabsf(tf), gr.pe1, gr.pe0), ms);
+    // level 0: |sigma N / norm| <= amax sn everywhere in the block
+    if (fabsf(mean) > e_amax * gr.sn * 1.0001f + ms + 4e-6f * fabsf(mean) + 1e-7f)
+        return mean > 0.f ? 1 : -1;
+    // level 1
+    const float wx = tx - fx0, wy = ty - fy0, wz = tz - fz0;
+    const uint32_t row = __umul24(ix, side) + iy;
+    gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)row * side + iz);
+    gfloat_p p01 = p00 + side, p10 = p00 + (size_t)side * side, p11 = p10 + side;
+    const float a000 = p00[0], a001 = p00[1], a010 = p01[0], a011 = p01[1];
+    const float a100 = p10[0], a101 = p10[1], a110 = p11[0], a111 = p11[1];
+    const float c00 = __builtin_fmaf(a001 - a000, wz, a000), c01 = __builtin_fmaf(a011 - a010, wz, a010);
+    const float c10 = __builtin_fmaf(a101 - a100, wz, a100), c11 = __builtin_fmaf(a111 - a110, wz, a110);
+    const float c0 = __builtin_fmaf(c01 - c00, wy, c00), c1 = __builtin_fmaf(c11 - c10, wy, c10);
+    const float g = __builtin_fmaf(c1 - c0, wx, c0);
     const float nv = g * gr.sn;
     const float fa = nv + mean;
     // 4e-6 relative also covers sigma*(g/norm) vs g*(sigma/norm) and the product roundings
-    const float margin = err * gr.sn * 1.0001f + ms + 4e-6f * (fabsf(nv) + fabsf(mean)) + 1e-7f;
+    const float margin = e_err * gr.sn * 1.0001f + ms + 4e-6f * (fabsf(nv) + fabsf(mean)) + 1e-7f;
     if (fa > margin) return 1;
     if (fa < -margin) return -1;
     return 0;
@@ -825,12 +875,14 @@ inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTab
     const size_t npts = (size_t)F->side * F->side * F->side;
     const size_t nblk = npts / 64;
     if (hipMalloc(&F->G, npts * sizeof(float)) != hipSuccess) { F->G = nullptr; (void)hipGetLastError(); return GPIS_ERR_DEVICE; }
-    if (hipMalloc(&F->err, nblk * sizeof(float)) != hipSuccess) { F->err = nullptr; guide_free(F); (void)hipGetLastError(); return GPIS_ERR_DEVICE; }
+    if (hipMalloc(&F->err, 2 * nblk * sizeof(float)) != hipSuccess) { F->err = nullptr; guide_free(F); (void)hipGetLastError(); return GPIS_ERR_DEVICE; }
     const size_t per_launch = (size_t)1 << 22;   // slabs of 4 Mi blocks
     for (size_t b0 = 0; b0 < nblk; b0 += per_launch) {
         const size_t nb = nblk - b0 < per_launch ? nblk - b0 : per_launch;
         k_guide_build<<<(unsigned)nb, 64>>>(d_model, T, *F, b0);
     }
+    for (size_t b0 = 0; b0 < nblk; b0 += (size_t)1 << 30)     // second pass: the blocks' bounds on |N| (reads every sample of the field)
+        k_guide_amax<<<(unsigned)(((nblk - b0 < ((size_t)1 << 30) ? nblk - b0 : ((size_t)1 << 30)) + 255) / 256), 256>>>(*F, b0, nblk);
     if (hipDeviceSynchronize() != hipSuccess) { guide_free(F); return GPIS_ERR_DEVICE; }
     F->enabled = 1;
     return GPIS_OK;
