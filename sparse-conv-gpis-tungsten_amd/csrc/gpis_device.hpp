@@ -420,6 +420,8 @@ struct FastLds {
     float4 chain[64];
     // lane tables of the two-way candidate split (coop_noise3d): the r-th lane with a query / the r-th lane without one
     uint32_t owner_tab[64], idle_tab[64];
+    // k-way candidate split (coop_noise3d_ksplit): the values of one pass, group-major (group g, helper j at g*k + j)
+    float4 exch[16];
 };
 constexpr int kChainGroups = 64;
 template <class LDS>

@@ -124,6 +124,18 @@ __device__ unsigned long long g_fast_stats[32];
 #endif
 
 constexpr int kFastBlock = 64;          // one wave per workgroup
+#ifndef GPIS_KSPLIT
+#define GPIS_KSPLIT 1
+#endif
+#ifndef GPIS_KSPLIT_MAXLG
+#define GPIS_KSPLIT_MAXLG 4
+#endif
+constexpr int kKSplitMaxLg = GPIS_KSPLIT_MAXLG;   // at most 2^this lanes per query
+#ifndef GPIS_KSPLIT_MAXNA
+#define GPIS_KSPLIT_MAXNA 16
+#endif
+constexpr int kKSplitMaxNa = GPIS_KSPLIT_MAXNA;   // clusters above this size keep the two-way split (one ds_bpermute per pass beats the LDS exchange at k = 2)
+constexpr bool kKSplit = GPIS_KSPLIT != 0;   // clusters of at most 32 queries: k-way candidate split (coop_noise3d_ksplit) instead of the two-way one
 #ifndef GPIS_FAST_OCC
 #define GPIS_FAST_OCC 3                 // waves per SIMD the register allocator must leave room for
 #endif
@@ -381,6 +393,169 @@ GPIS_DEV V4 coop_noise3d(const DevModel &M, const FastTable &T, FastLds &lds, bo
     return sum;
 }
 
+// ---- k-way candidate split ------------------------------------------------------------------------------------------------
+// The exact rounds of the guided march serve clusters of 1 ... 64 lanes (31 on average; 28 % of the rounds at most 16, 29 % at most
+// 3).  A cooperative evaluation costs the same whatever the number of queries: every candidate impulse (~145) runs the kernel body
+// on every lane.  Here the na <= 32 queries of a cluster are spread over the whole wave: k = 2, 4, 8 or 16 lanes per query (the
+// owner + k-1 idle lanes working on copies of its query point).  Per lattice cell the candidates are compacted into LDS in ascending
+// impulse order; in pass p the j-th lane of every group evaluates candidate p k + j, the k values of a group meet in LDS, and the
+// owner adds them in order:  cell = (...((cell + c(pk)) + c(pk+1)) + ...) — the reference's own sequence (SCN.cpp:383-392), a
+// missing candidate contributing +0, which is exact.  ceil(n / k) kernel bodies per lane instead of n.
+// Measured on C1 (Msamples/s; 420.8 without it): used for every cluster <= 32 and instead of the sideways evaluator 416.8 / 403;
+// next to the sideways evaluator (clusters <= 3) 426; and with the two-way split kept for 17 ... 32 queries (its exchange is one
+// ds_bpermute) 428.9 — the default: sideways <= 3 queries, k = 16 / 8 / 4 for 4 / 5-8 / 9-16, two-way 17-32, unsplit above.
+template <bool SMALLARG>
+GPIS_DEV float coop_noise3d_ksplit(const DevModel &M, const FastTable &T, FastLds &lds, bool active, V3 p, uint32_t seed, float R, float A0, float A1, float A2)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const V3 pg = p / R;
+    const V3 fl = v3(floorf(pg.x), floorf(pg.y), floorf(pg.z));
+    V3 frac = pg - fl;
+    int ci0 = (int)fl.x, cj0 = (int)fl.y, ck0 = (int)fl.z;
+    const unsigned long long am = __ballot(active);
+    const int na = __popcll(am);
+    if (na == 0)
+        return 0.f;
+    // bounding box of the queries (owners only)
+    const float big = 3.0e38f;
+    const float bx0 = uni_f(wave_min_f(active ? pg.x : big)), bx1 = uni_f(wave_max_f(active ? pg.x : -big));
+    const float by0 = uni_f(wave_min_f(active ? pg.y : big)), by1 = uni_f(wave_max_f(active ? pg.y : -big));
+    const float bz0 = uni_f(wave_min_f(active ? pg.z : big)), bz1 = uni_f(wave_max_f(active ? pg.z : -big));
+    const float lim = 1.0e6f;
+    const bool sane = bx0 > -lim && bx1 < lim && by0 > -lim && by1 < lim && bz0 > -lim && bz1 < lim;
+    int ilo = 0, ihi = 0, jlo = 0, jhi = 0, klo = 0, khi = 0;
+    if (sane) {
+        ilo = (int)floorf(bx0); ihi = (int)floorf(bx1);
+        jlo = (int)floorf(by0); jhi = (int)floorf(by1);
+        klo = (int)floorf(bz0); khi = (int)floorf(bz1);
+    }
+    if (!(sane && (ihi - ilo) <= 1 && (jhi - jlo) <= 1 && (khi - klo) <= 1) || na > 32) {
+        // incoherent cluster, non-finite input or nothing to split: every lane generates its own impulses
+        float r = 0.f;
+        if (active)
+            r = noise3d_per_lane(M, p, seed, R, A0, A1, A2).v;
+        return r;
+    }
+    // k = lanes per query: 2 (17..32 queries), 4 (9..16), 8 (5..8), 16 (1..4); G2 = 64 / k groups, the first na in use
+    const int lgk0 = na > 16 ? 1 : na > 8 ? 2 : na > 4 ? 3 : 4;
+    const int lgk = lgk0 < kKSplitMaxLg ? lgk0 : kKSplitMaxLg;
+    const int k = 1 << lgk, lgG = 6 - lgk, G2 = 1 << lgG;
+    const int rank_a = __popcll(am & ((1ULL << lane) - 1ULL)), rank_i = lane - rank_a;
+    // owner: group rank_a, member 0.  idle lane of rank r: group r mod G2, member 1 + r / G2
+    const int grp = active ? rank_a : (rank_i & (G2 - 1));
+    const int mem = active ? 0 : 1 + (rank_i >> lgG);
+    const bool helper = !active && grp < na && mem < k;
+    const bool act2 = active || helper;
+    if (active) lds.owner_tab[rank_a] = (uint32_t)lane;
+    // one wave per workgroup and in-order LDS: only the compiler has to be told that lanes talk to each other here
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int owner = helper ? (int)lds.owner_tab[grp] : lane;
+        const float hx = __shfl(frac.x, owner, 64), hy = __shfl(frac.y, owner, 64), hz = __shfl(frac.z, owner, 64);
+        const int hi = __shfl(ci0, owner, 64), hj = __shfl(cj0, owner, 64), hk = __shfl(ck0, owner, 64);
+        if (helper) { frac = v3(hx, hy, hz); ci0 = hi; cj0 = hj; ck0 = hk; }
+    }
+    const int slot = (grp << lgk) + mem;                  // this lane's place in lds.exch (as floats)
+    float *const exch = reinterpret_cast<float *>(lds.exch);
+
+    const uint32_t n = M.n_impulses;
+    const int nj = jhi - jlo + 3, nk = khi - klo + 3;
+    const int total = (ihi - ilo + 3) * nj * nk;          // 27 .. 64 cells
+    const int H = T.half, S = T.stride;
+    const unsigned side = 2u * (unsigned)H;
+    const float4 *cells = T.cells;
+    auto in_table = [&](int ci, int cj, int ck) {
+        return cells && (unsigned)(ci + H) < side && (unsigned)(cj + H) < side && (unsigned)(ck + H) < side;
+    };
+    auto fetch = [&](int ci, int cj, int ck) {
+        const uint32_t idx = (((uint32_t)(ci + H) * side + (uint32_t)(cj + H)) * side + (uint32_t)(ck + H)) * (uint32_t)S;
+        return cells[idx + (uint32_t)(lane & (S - 1))];
+    };
+    int ci = ilo - 1, cj = jlo - 1, ck = klo - 1;
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_table(ci, cj, ck))
+        nxt = fetch(ci, cj, ck);
+    float sum = 0.f;
+    for (int c = 0; c < total; ++c) {
+        const int ti = ci, tj = cj, tk = ck;             // this cell
+        const float4 cur = nxt;
+        if (++ck > khi + 1) { ck = klo - 1; if (++cj > jhi + 1) { cj = jlo - 1; ++ci; } }
+        if (c + 1 < total && in_table(ci, cj, ck))
+            nxt = fetch(ci, cj, ck);
+        const int di = ti - ci0, dj = tj - cj0, dk = tk - ck0;
+        const bool mine = act2 && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
+        if (__ballot(mine) == 0ULL)
+            continue;
+        float px, py, pz, pw;
+        if (in_table(ti, tj, tk)) {
+            px = cur.x; py = cur.y; pz = cur.z; pw = cur.w;
+        } else {
+            gen_impulse((uint32_t)ti, (uint32_t)tj, (uint32_t)tk, seed, kJump4.A[lane], kJump4.C[lane], px, py, pz, pw);
+        }
+        // cull: sphere (radius 1) vs box-of-queries distance, with slack for the differently rounded test
+        const float qx0 = bx0 - (float)ti, qx1 = bx1 - (float)ti;
+        const float qy0 = by0 - (float)tj, qy1 = by1 - (float)tj;
+        const float qz0 = bz0 - (float)tk, qz1 = bz1 - (float)tk;
+        const float gx = fmaxf(fmaxf(qx0 - px, px - qx1), 0.f);
+        const float gy = fmaxf(fmaxf(qy0 - py, py - qy1), 0.f);
+        const float gz = fmaxf(fmaxf(qz0 - pz, pz - qz1), 0.f);
+        const bool cand_k = (uint32_t)lane < n && (gx * gx + gy * gy + gz * gz) < 1.0001f;
+        const unsigned long long cand = __ballot(cand_k);
+        if (cand == 0ULL)
+            continue;
+        const int cnt = __popcll(cand);
+        // the candidates, compacted in ascending impulse order, in the layout the packed body consumes
+        if (cand_k) {
+            const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cand >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cand, 0u));
+            lds.xyr[r] = make_float4(px, py, R * px, R * py);
+            lds.zw[r] = make_float4(pz, R * pz, pw, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // lanes whose neighbourhood does not contain this cell get a far-away point: the unit-ball test fails for them
+        const V3 pc = mine ? frac - v3((float)di, (float)dj, (float)dk) : v3(8.f, 8.f, 8.f);
+        const V3 Rp = R * pc;
+        const float2v pcxy = float2v{pc.x, pc.y}, Rpxy = float2v{Rp.x, Rp.y}, pzRz = float2v{pc.z, Rp.z}, Axy = float2v{A0, A1};
+        float cell = 0.f;
+        for (int base = 0; base < cnt; base += k) {
+            const int idx = base + mem;
+            const bool valid = act2 && idx < cnt;
+            const float4 qa = lds.xyr[idx & 63], qb = lds.zw[idx & 63];
+            const float2v ixy = float2v{qa.x, qa.y}, rxy = float2v{qa.z, qa.w}, zrz = float2v{qb.x, qb.y};
+            const float2v dxy = pcxy - ixy;             // (pc.x - x, pc.y - y)
+            const float2v abxy = Rpxy - rxy;            // (ab.x, ab.y)
+            const float2v dzab = pzRz - zrz;            // (pc.z - z, ab.z)
+            const float2v d2 = dxy * dxy;
+            const float2v txy = abxy * Axy;             // (t.x, t.y)
+            const float2v tab = txy * abxy;
+            const float tz = dzab.y * A2;
+            const float2v zz = float2v{dzab.x, tz} * dzab;     // (dz^2, t.z * ab.z)
+            const bool pass = valid && ((d2.x + d2.y) + zz.x) < 1.0f;
+            const float absq = tab.x + (tab.y + zz.y);
+            const float f = expf_glibc_lds<true, SMALLARG>(lds, -absq);
+            if (act2)
+                exch[slot] = pass ? qb.z * f : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // the group's k values in candidate order (lanes of a group read the same addresses; only the owner's sum is used)
+            if (lgk == 1) {
+                const float2 v = *reinterpret_cast<const float2 *>(exch + (grp << 1));
+                cell = (cell + v.x) + v.y;
+            } else {
+                for (int i = 0; i < k; i += 4) {
+                    const float4 v = lds.exch[((grp << lgk) + i) >> 2];
+                    cell = (((cell + v.x) + v.y) + v.z) + v.w;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        sum = sum + cell;
+    }
+    return sum;
+}
+
 // noise3D VALUE for ONE query (the one held by lane `src`, src wave-uniform) with the wave turned
 // sideways: lane k owns impulse k of the current cell and evaluates its kernel against the single query
 // point; the cell sum is then accumulated over the passing lanes in ascending k (ChainSum: compacted into LDS
@@ -511,10 +686,14 @@ GPIS_DEV V4 coop_eval_noise3d(const DevModel &M, const FastTable &T, FastLds &ld
         float R = M.radius_world;
         // getInvCovMtx(isCov=false, isIsotropic=false, globalScale=1, localScale=1): ((A / 1) / 1) * 0.5
         float A0 = M.invcov_world[0] / 1.f / 1.f * 0.5f, A1 = M.invcov_world[4] / 1.f / 1.f * 0.5f, A2 = M.invcov_world[8] / 1.f / 1.f * 0.5f;
+        if (!GRAD && kKSplit && split && __popcll(__ballot(active)) <= kKSplitMaxNa)
+            return v4(coop_noise3d_ksplit<SMALLARG>(M, T, lds, active, p, M.seed, R, A0, A1, A2) / M.norm3d_world, 0.f, 0.f, 0.f);
         V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p, M.seed, R, A0, A1, A2, split);
         return nz / M.norm3d_world;
     }
     V3 p_iso_ray = to_local(coord, spec_3d::cov_pos_w2l(M, p, 1.0f));
+    if (!GRAD && kKSplit && split && __popcll(__ballot(active)) <= kKSplitMaxNa)
+        return v4(coop_noise3d_ksplit<SMALLARG>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f) / M.norm3d_iso, 0.f, 0.f, 0.f);
     V4 nz = coop_noise3d<GRAD, SMALLARG>(M, T, lds, active, p_iso_ray, M.seed, M.radius_iso, 0.5f, 0.5f, 0.5f, split);
     if (GRAD) {
         V3 gw = spec_3d::cov_grad_l2w(M, to_global(coord, v3(nz.gx, nz.gy, nz.gz)), 1.0f);

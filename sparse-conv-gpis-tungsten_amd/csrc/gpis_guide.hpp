@@ -73,7 +73,11 @@ struct GuideField {
 #endif
 constexpr bool kSoloPacked = GPIS_SOLO_PACKED != 0;   // sideways evaluator with 64 / stride cells per pass (measured slower in the resident kernels: C1 403 vs 412 Msamples/s)
 constexpr bool kGuideSplit = GPIS_GUIDE_SPLIT != 0;   // two-way candidate split for clusters of at most 32 lanes
-constexpr int kSoloMaxLanes = GPIS_SOLO_MAX;   // clusters up to this size use the sideways evaluator
+constexpr int kSoloMaxLanes = GPIS_SOLO_MAX;   // clusters up to this size use the sideways evaluator (range / wavefront kernels)
+#ifndef GPIS_GUIDE_SOLO_MAX
+#define GPIS_GUIDE_SOLO_MAX GPIS_SOLO_MAX
+#endif
+constexpr int kGuideSoloMax = GPIS_GUIDE_SOLO_MAX;   // the same in the resident guided kernels (0: the k-way split serves the smallest clusters too — measured slower, 403 vs 429)
 constexpr float kGuidePosEps = 1e-4f;         // bound on |u - w| per axis (cells): measured < 2e-5, see GuideRay
 constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the block's cells an impulse contributes exactly 0
 
@@ -596,7 +600,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
         const unsigned long long cl_mask = __ballot(in_cluster);
         FSTAT(22, 1);
         FSTAT(23, __popcll(need_mask));
-        if (__popcll(cl_mask) <= kSoloMaxLanes) {
+        if (__popcll(cl_mask) <= kGuideSoloMax) {
             // few requests: one sideways (lane = impulse) evaluation per requesting lane
             FSTAT(24, 1);
             FSTAT(25, __popcll(cl_mask));
