@@ -31,7 +31,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md "Chip-le
 B_SEG = 224                    # bytes per segment: 128 in + 96 out
 N_SIMD = 256 * 4               # CUs x SIMDs
 PEAK_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md "Max clock"
-ISSUE_MODEL = os.path.join(ROOT, "profiles", "r02_issue_model.json")
 
 
 def algorithmic_bytes_per_eval(params):
@@ -67,7 +66,7 @@ def issue_roofline(kernel, workload_key, avg_launch_ms, lib_path):
     deterministic for it.  `traffic` = FETCH_SIZE + WRITE_SIZE of the same launch."""
     import glob
     model, k, src = None, None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_issue_model*.json"))):     # one file per profiled workload
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_issue_model*.json")), reverse=True):     # one file per profiled workload, the latest round first
         try:
             cand = json.load(open(path))
         except Exception:
@@ -313,15 +312,22 @@ def main():
     prof = [med.kernel_profile(k) for k in (0, 1)]     # (ms, launches, n_eval, n_seg)
     n_guide = med.guide_steps() if guide_info else 0
 
-    # ---- the same frame without the guide field: every march step evaluated exactly (N = 1 only; one frame)
-    dt_unguided = None
+    # ---- the same frame without the guide field: every march step evaluated exactly (N = 1 only; one frame) — and the
+    #      run's own parity check: the guided frame that was timed must equal this one bit for bit (the certificate only ever
+    #      replaces evaluations whose sign it has proven, SCNM.cpp:132-174), otherwise the bench fails
+    dt_unguided, frame_bit_identical = None, None
     if guide_info and world == 1 and not args.no_unguided:
+        rad_guided = rad.clone()
         med.drop_guide()
         fence()
         t1 = time.perf_counter()
         step()
         fence()
         dt_unguided = time.perf_counter() - t1
+        frame_bit_identical = bool(torch.equal(rad, rad_guided))
+        if not frame_bit_identical:
+            n_diff = int((rad != rad_guided).sum().item())
+            print("bench.py: the guided frame differs from the unguided frame in %d of %d pixels" % (n_diff, rad.numel()), file=sys.stderr)
 
     if rank == 0:
         samples_per_step = W * H * pkg.dist.total_spp(scene, world, args.shard)
@@ -355,6 +361,7 @@ def main():
             "metric": "Msamples/s (primary rays x spp / s)", "value": total_samples / dt_max / 1e6, "unit": "Msamples/s",
             "value_cold": samples_per_step / dt_cold_max / 1e6,
             "value_unguided": (samples_per_step / dt_unguided / 1e6) if dt_unguided else None,
+            "frame_bit_identical": frame_bit_identical,
             "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.shard == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: scene S %dx%d, %d spp, SparseConvolutionNoiseMedium (3D isotropic, "
@@ -376,6 +383,8 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+    if frame_bit_identical is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

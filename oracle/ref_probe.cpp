@@ -245,3 +245,149 @@ float ref_uniform_spherical_cap_pdf(float cosThetaMax) { return SampleWarp::unif
 float ref_inv_pi_float(void) { return INV_PI; }
 
 } // extern "C"
+
+// =========================================================================================
+// Round 3: the function-space path's linear-algebra / sampling layer and the fbm noise,
+// straight from the reference's own sources and its vendored Eigen (no stand-ins):
+//   * MultivariateNormalDistribution ctor + sample()   (src/core/sampling/Gaussian.cpp:121-167, 179-232)
+//     with sampling/UniformPathSampler.hpp as the PathSampleGenerator
+//   * Eigen::SelfAdjointEigenSolver<MatrixXd> (compute and computeFromTridiagonal), Eigen::LLT<MatrixXd>
+//     (src/thirdparty/eigen/Eigen/src/Eigenvalues/SelfAdjointEigenSolver.h, Cholesky/LLT.h)
+//   * the expression forms of pseudo_inverse (src/core/math/GaussianProcess.cpp:645-662; that TU itself
+//     includes GPFunctions.hpp -> Boost and cannot be built, so only its Eigen expressions are evaluated here)
+//   * fbm / simplex3d / random3 (src/core/math/SdfFunctions.cpp:199-296; linked from that TU)
+// =========================================================================================
+#include "sampling/UniformPathSampler.hpp"
+#include "math/SdfFunctions.hpp"
+#include <cfloat>
+
+namespace Tungsten {
+float simplex3d(Vec3f p);      // defined (external linkage) in math/SdfFunctions.cpp:228
+Vec3f random3(Vec3f c);        // math/SdfFunctions.cpp:199
+}
+
+static inline Eigen::MatrixXd loadMd(int n, int m, const double *a)
+{
+    return Eigen::Map<const Eigen::MatrixXd>(a, n, m);      // column-major
+}
+
+extern "C" {
+
+// SelfAdjointEigenSolver<MatrixXd>(A): eigenvectors (column-major) and eigenvalues; returns info()
+int ref_fs_eigh(int n, const double *A, double *evecs, double *evals)
+{
+    Eigen::MatrixXd M = loadMd(n, n, A);
+    Eigen::SelfAdjointEigenSolver<Eigen::MatrixXd> eigs(M);
+    Eigen::Map<Eigen::MatrixXd>(evecs, n, n) = eigs.eigenvectors();
+    Eigen::Map<Eigen::VectorXd>(evals, n) = eigs.eigenvalues();
+    return (int)eigs.info();
+}
+// the implicit symmetric QR iteration alone, on a given tridiagonal matrix (eigenvector accumulation starts from I)
+int ref_fs_eigh_tridiagonal(int n, const double *diag, const double *sub, double *evecs, double *evals)
+{
+    Eigen::VectorXd d = Eigen::Map<const Eigen::VectorXd>(diag, n);
+    Eigen::VectorXd s = Eigen::Map<const Eigen::VectorXd>(sub, n - 1);
+    Eigen::SelfAdjointEigenSolver<Eigen::MatrixXd> eigs;
+    eigs.computeFromTridiagonal(d, s, Eigen::ComputeEigenvectors);
+    Eigen::Map<Eigen::MatrixXd>(evecs, n, n) = eigs.eigenvectors();
+    Eigen::Map<Eigen::VectorXd>(evals, n) = eigs.eigenvalues();
+    return (int)eigs.info();
+}
+// Tridiagonalization of the solver's first phase: diag, sub-diagonal and Q of internal::tridiagonalization_inplace
+// on the scaled lower triangle, as SelfAdjointEigenSolver::compute runs it (SelfAdjointEigenSolver.h:441-452)
+void ref_fs_tridiagonalize(int n, const double *A, double *diag, double *sub, double *Q, double *scale_out)
+{
+    Eigen::MatrixXd mat = loadMd(n, n, A).triangularView<Eigen::Lower>();
+    double scale = mat.cwiseAbs().maxCoeff();
+    if (scale == 0.0) scale = 1.0;
+    mat.triangularView<Eigen::Lower>() /= scale;
+    Eigen::VectorXd d(n), s(n - 1);
+    Eigen::VectorXd hCoeffs(n - 1);
+    Eigen::VectorXd workspace(n);
+    Eigen::internal::tridiagonalization_inplace(mat, d, s, hCoeffs, workspace, true);
+    Eigen::Map<Eigen::VectorXd>(diag, n) = d;
+    Eigen::Map<Eigen::VectorXd>(sub, n - 1) = s;
+    Eigen::Map<Eigen::MatrixXd>(Q, n, n) = mat;
+    *scale_out = scale;
+}
+// LLT<MatrixXd>(S.triangularView<Lower>()): matrixL (dense, column-major); returns info()
+int ref_fs_llt(int n, const double *S, double *L)
+{
+    Eigen::MatrixXd M = loadMd(n, n, S);
+    Eigen::LLT<Eigen::MatrixXd> chol(M.triangularView<Eigen::Lower>());
+    Eigen::MatrixXd l = chol.matrixL();
+    Eigen::Map<Eigen::MatrixXd>(L, n, n) = l;
+    return (int)chol.info();
+}
+// MultivariateNormalDistribution(mean, cov).normTransform
+void ref_mvn_norm_transform(int n, const double *mean, const double *cov, double *T)
+{
+    Eigen::VectorXd mu = Eigen::Map<const Eigen::VectorXd>(mean, n);
+    Eigen::MatrixXd S = loadMd(n, n, cov);
+    MultivariateNormalDistribution mvn(mu, S);
+    Eigen::Map<Eigen::MatrixXd>(T, n, n) = mvn.normTransform;
+}
+// MultivariateNormalDistribution(mean, cov).sample(constraints, numConstraints, samples, UniformPathSampler(UniformSampler after set_state))
+// constraints: numConstraints x {startIdx, endIdx} ints + {minV, maxV} floats.  out: n x samples column-major.
+// state_out: the sampler's state afterwards (how many draws were consumed).
+void ref_mvn_sample(int n, const double *mean, const double *cov, uint64_t state, int numConstraints, const int *cidx, const float *cminmax,
+                    int samples, double *out, uint64_t *state_out)
+{
+    Eigen::VectorXd mu = Eigen::Map<const Eigen::VectorXd>(mean, n);
+    Eigen::MatrixXd S = loadMd(n, n, cov);
+    MultivariateNormalDistribution mvn(mu, S);
+    UniformSampler us;
+    us.set_state(state);
+    UniformPathSampler ps(us);
+    std::vector<Constraint> cs(numConstraints);
+    for (int i = 0; i < numConstraints; ++i)
+        cs[i] = Constraint{cidx[2 * i], cidx[2 * i + 1], cminmax[2 * i], cminmax[2 * i + 1]};
+    Eigen::MatrixXd r = mvn.sample(cs.data(), numConstraints, samples, ps);
+    Eigen::Map<Eigen::MatrixXd>(out, n, samples) = r;
+    if (state_out) *state_out = ps.uniformGenerator().state();
+}
+// rand_truncated_normal(mean, sigma, a, sampler)  (Gaussian.cpp:57-85)
+double ref_rand_truncated_normal(double mean, double sigma, double a, uint64_t state, uint64_t *state_out)
+{
+    UniformSampler us;
+    us.set_state(state);
+    UniformPathSampler ps(us);
+    double r = rand_truncated_normal(mean, sigma, a, ps);
+    if (state_out) *state_out = ps.uniformGenerator().state();
+    return r;
+}
+// the Eigen expressions of pseudo_inverse (GaussianProcess.cpp:645-662), written as there
+void ref_fs_pinv_forms(int n, const double *A, double *out)
+{
+    Eigen::MatrixXd a = loadMd(n, n, A);
+    Eigen::SelfAdjointEigenSolver<Eigen::MatrixXd> eigs(a);
+    double eps = 1e6 * DBL_EPSILON * eigs.eigenvalues().cwiseAbs().maxCoeff();
+    Eigen::VectorXd v = eigs.eigenvalues();
+    Eigen::VectorXd s_pinv = v.cwiseAbs().cwiseLessOrEqual(eps).select(0., v.cwiseInverse());
+    Eigen::MatrixXd U = eigs.eigenvectors() * s_pinv.cwiseSqrt().asDiagonal();
+    Eigen::MatrixXd r = U * U.transpose();
+    Eigen::Map<Eigen::MatrixXd>(out, n, n) = r;
+}
+// create_mvn_cond's dense products, as written at GaussianProcess.cpp:722-735:
+//   solved = (pinv * s12).transpose();  mean += solved * resid;  cov = s22 - solved * s12
+void ref_fs_cond_forms(int nc, int n, const double *pinv, const double *s12, const double *s22, const double *resid, const double *mean,
+                       double *mean_out, double *cov_out)
+{
+    Eigen::MatrixXd P = loadMd(nc, nc, pinv), S12 = loadMd(nc, n, s12), S22 = loadMd(n, n, s22);
+    Eigen::VectorXd r = Eigen::Map<const Eigen::VectorXd>(resid, nc), mu = Eigen::Map<const Eigen::VectorXd>(mean, n);
+    Eigen::MatrixXd solved = (P * S12).transpose();
+    Eigen::VectorXd m2 = mu + (solved * r);
+    Eigen::MatrixXd c2 = S22 - (solved * S12);
+    Eigen::Map<Eigen::VectorXd>(mean_out, n) = m2;
+    Eigen::Map<Eigen::MatrixXd>(cov_out, n, n) = c2;
+}
+
+double ref_fbm(const double *uv, int octaves) { return fbm(Vec3d(uv[0], uv[1], uv[2]), octaves); }
+float ref_simplex3d(const float *p) { return simplex3d(Vec3f(p[0], p[1], p[2])); }
+void ref_random3(const float *c, float *out)
+{
+    Vec3f r = random3(Vec3f(c[0], c[1], c[2]));
+    out[0] = r.x(); out[1] = r.y(); out[2] = r.z();
+}
+
+} // extern "C"

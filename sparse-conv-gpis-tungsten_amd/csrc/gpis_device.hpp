@@ -26,6 +26,9 @@
 namespace gpis {
 
 #define GPIS_DEV __device__ __forceinline__
+// a kernel defined in a header shared by several translation units is a template on a dummy parameter, so that only
+// the TU that launches it (k<0><<<...>>>) instantiates and compiles it (gpis_launch.hpp)
+#define GPIS_TU_KERNEL template <int TU_ = 0>
 
 constexpr int kLevelMin = -24;
 constexpr int kLevelMax = 24;

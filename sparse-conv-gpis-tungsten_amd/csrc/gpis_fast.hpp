@@ -47,7 +47,7 @@ inline bool fast_supported(const DevModel &M)
     return M.single_realization && !M.sampling_1d && !M.nonstationary && !M.use_aniso_mtx && !M.absorption_only && !M.color.enabled && M.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL &&
            M.n_impulses >= 1 && M.n_impulses <= 64;
 }
-__global__ void __launch_bounds__(64) k_fast_build_table(uint32_t seed, int half, int stride, float4 *__restrict__ cells)
+GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_fast_build_table(uint32_t seed, int half, int stride, float4 *__restrict__ cells)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int side = 2 * half;
@@ -77,7 +77,7 @@ inline int fast_table_build(const DevModel &M, const DevModel *, FastTable *t)
         (void)hipGetLastError();
         return GPIS_OK;
     }
-    k_fast_build_table<<<(unsigned)ncell, 64>>>(M.seed, half, stride, t->cells);
+    k_fast_build_table<0><<<(unsigned)ncell, 64>>>(M.seed, half, stride, t->cells);
     if (hipDeviceSynchronize() != hipSuccess) {
         (void)hipFree(t->cells);
         t->cells = nullptr;
@@ -115,7 +115,7 @@ GPIS_DEV float wave_max_f(float v)
 #endif
 #define GPIS_KEEP(x) asm volatile("" ::"v"(x))
 #ifdef GPIS_FAST_STATS
-__device__ unsigned long long g_fast_stats[32];
+static __device__ unsigned long long g_fast_stats[32];   // one copy per translation unit (diagnostic builds)
 #define FSTAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fast_stats[i], (unsigned long long)(v)); } while (0)
 #define FCLK() ((long long)__builtin_readcyclecounter())
 #else
@@ -966,7 +966,7 @@ __device__ __forceinline__ void fast_flush_counters(Counters *cnt, uint32_t n_ev
     }
 }
 
-__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_fast_sample_distance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
+GPIS_TU_KERNEL __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_fast_sample_distance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
                                                                     gpis_seg_out *__restrict__ out, gpis_cond_coeff *__restrict__ coeff,
                                                                     const uint8_t *__restrict__ mask, Counters *cnt)
 {
@@ -986,7 +986,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_fast_sample_dista
     fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
 }
 
-__global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_fast_transmittance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
+GPIS_TU_KERNEL __global__ void __launch_bounds__(kFastBlock, GPIS_FAST_OCC) k_fast_transmittance(const DevModel *__restrict__ Mp, FastTable T, size_t n, const gpis_ray_in *__restrict__ rays,
                                                                   uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
 {
     __shared__ FastLds lds;
@@ -1005,14 +1005,14 @@ inline int fast_sample_distance(const DevModel *d_model, const FastTable *T, siz
                                 gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, hipStream_t s)
 {
     unsigned grid = (unsigned)((n + kFastBlock - 1) / kFastBlock);
-    k_fast_sample_distance<<<grid, kFastBlock, 0, s>>>(d_model, *T, n, rays, out, coeff, mask, cnt);
+    k_fast_sample_distance<0><<<grid, kFastBlock, 0, s>>>(d_model, *T, n, rays, out, coeff, mask, cnt);
     return GPIS_OK;
 }
 inline int fast_transmittance(const DevModel *d_model, const FastTable *T, size_t n, const gpis_ray_in *rays, uint8_t *visible,
                               const uint8_t *mask, Counters *cnt, hipStream_t s)
 {
     unsigned grid = (unsigned)((n + kFastBlock - 1) / kFastBlock);
-    k_fast_transmittance<<<grid, kFastBlock, 0, s>>>(d_model, *T, n, rays, visible, mask, cnt);
+    k_fast_transmittance<0><<<grid, kFastBlock, 0, s>>>(d_model, *T, n, rays, visible, mask, cnt);
     return GPIS_OK;
 }
 

@@ -89,7 +89,7 @@ constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the b
 // r_i(c) - m >= r_i(cB) - mB).  Only the impulses whose cut-off sphere passes near the block take the per-cell
 // classification of the header comment.  (Before: every pair took it, 100 instructions with a correctly rounded sqrtf and four
 // v_readlane; 2.5 s for the 34 GB field.)
-__global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t block_offset)
+GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t block_offset)
 {
     __shared__ float4 stage[64];
     const DevModel &M = *Mp;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__
 // layer belongs to the neighbouring blocks) + Err(block).  The interpolant of a cell is a convex combination of its corners, so
 // |N_ref(u)| <= |G(u)| + Err <= amax for every u the march can look up in the block: when the mean alone exceeds sigma amax / norm
 // the sign of the field is the sign of the mean, and the march skips the 8-tap lookup (guide_sign_at, level 0).
-__global__ void __launch_bounds__(256) k_guide_amax(GuideField F, size_t block_offset, size_t nblk)
+GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_amax(GuideField F, size_t block_offset, size_t nblk)
 {
     const size_t b = block_offset + (size_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= nblk)
@@ -349,24 +349,33 @@ GPIS_DEV int guide_sign(const DevModel &M, const GuideField &F, V3 p, const Fram
 // The march visits p(t) = pos + t*dir, and the grid position is a LINEAR map of p (iso-ray space: rotation into the
 // ray frame of the whitened position; world space: p / R), so the index-space coordinates of a step are a + t*b with
 // a, b computed once per segment in double and kept in fp32; a step evaluates them with one fp32 fma each.
+// Both are ANCHORED at the segment start t0 = nearT (a = index coordinates of pos + t0 dir, steps use t - t0): the fp32
+// magnitudes |a| and |(t - t0) b| then stay of the order of the field's side whatever the distance of the ray origin from the
+// medium (with a = coordinates of `pos` itself an origin 500 world units away put |a| ~ 3e5 index units, i.e. 1.2e-4 cells
+// per rounding — outside the budget below).  A segment whose anchor is further than 200 lattice cells from the field's centre
+// (nearT far from the medium's bounds) is not certified at all (a = -3e38: the range check of every step fails).
 // Error of the lookup position against the position u the exact evaluator derives for the same t (the stored bound
-// carries kGuidePosEps = 1e-4 cells for it, k_guide_build): the roundings of a, b, (float)t and of the fma are each
-// <= 2^-24 of an index coordinate <= side, i.e. <= 4 x 2 half x 6e-8 cells = 3e-5 cells at half = 64 (8e-6 at 16); u itself
-// is a chain of ~8 fp32 roundings of |u| <= half cells (measured < 2e-5 at half = 16).  gpis_guide_raycheck walks real
-// rays and checks every certified sign against the exact value.
-// The mean is evaluated at pos + (float)t * dir in fp32; `pe0 + pe1 |t|` bounds its 1-norm distance from the exact
-// evaluator's float(pos_d + t dir_d): (|t - (float)t| |dir_c| + two roundings of |p_c|) summed over the components.
+// carries kGuidePosEps = 1e-4 cells for it, k_guide_build), in units of ppc index units = cells: |a| <= 200; inside the field
+// |a + ts b| <= 2 half <= 128, hence |ts b| <= 328.  Roundings: a (2^-24 x 200), ts = (float)(t - t0) and b (2^-24 x 328
+// each), the fma's result (2^-24 x 128): together 984 x 6e-8 = 5.9e-5 cells; u itself is a chain of ~8 fp32 roundings of
+// |u| <= half cells (measured < 2e-5 at half = 16).  gpis_guide_raycheck walks real rays — camera, shadow, and bundles
+// whose origins lie 15 (unanchored), 44, 500 and 2000 world units away — and checks every certified sign against the exact
+// value.
+// The mean is evaluated at pos0 + (float)(t - t0) * dir in fp32, pos0 = float(pos + t0 dir); `pe0 + pe1 |t - t0|` bounds
+// its 1-norm distance from the exact evaluator's float(pos_d + t dir_d): (|ts - (float)ts| |dir_c| + the roundings of
+// pos0_c, of the fma and of the exact position) summed over the components.
 struct GuideRay {
-    float ax, ay, az, bx, by, bz;    // index coordinates = a + t*b
-    V3 pos, dir;                     // the ray (world space)
-    float pe0, pe1;                  // position slack = pe0 + pe1 * |t|
+    float ax, ay, az, bx, by, bz;    // index coordinates = a + (t - t0)*b
+    V3 pos, dir;                     // the ray anchored at t0: pos = float(origin + t0 dir) (world space)
+    float t0;                        // = nearT (the march already holds it: no extra register)
+    float pe0, pe1;                  // position slack = pe0 + pe1 * |t - t0|
     float sn;                        // sigma / norm
 };
 
-GPIS_DEV GuideRay guide_ray(const DevModel &M, const GuideField &F, V3 pos, V3 dir, const Frame &coord)
+GPIS_DEV GuideRay guide_ray(const DevModel &M, const GuideField &F, V3 pos, V3 dir, const Frame &coord, float nearT)
 {
-    auto lin = [&](V3 v, double &x, double &y, double &z) {
-        double wx = (double)v.x, wy = (double)v.y, wz = (double)v.z;
+    auto lin = [&](V3d v, double &x, double &y, double &z) {
+        double wx = v.x, wy = v.y, wz = v.z;
         if (M.iso3d) {
             const float *m = M.w2l;    // stationary media only: cov_xf_scale == 1 (cov_pos_w2l)
             const double lx = (double)GM(m, 0, 0) * wx + (double)GM(m, 0, 1) * wy + (double)GM(m, 0, 2) * wz;
@@ -380,15 +389,21 @@ GPIS_DEV GuideRay guide_ray(const DevModel &M, const GuideField &F, V3 pos, V3 d
         x = wx * s; y = wy * s; z = wz * s;
     };
     double ax, ay, az, bx, by, bz;
-    lin(pos, ax, ay, az);
-    lin(dir, bx, by, bz);
-    const double off = (double)F.half * (double)F.ppc;
     GuideRay g;
-    g.ax = (float)(ax + off); g.ay = (float)(ay + off); g.az = (float)(az + off);
+    g.t0 = nearT;
+    const V3d pos0 = ray_at(to_d(pos), to_d(dir), (double)nearT);      // the segment's start, in double
+    lin(pos0, ax, ay, az);
+    lin(to_d(dir), bx, by, bz);
+    const double offd = (double)F.half * (double)F.ppc;
+    const float off = (float)offd;
+    g.ax = (float)(ax + offd); g.ay = (float)(ay + offd); g.az = (float)(az + offd);
+    const float far = 200.f * (float)F.ppc, mid = off;      // |anchor - field centre| <= 200 cells per axis
+    if (!(fabsf(g.ax - mid) <= far && fabsf(g.ay - mid) <= far && fabsf(g.az - mid) <= far))
+        g.ax = -3e38f;               // anchor far from the field: no step of this segment passes the range check
     g.bx = (float)bx; g.by = (float)by; g.bz = (float)bz;
-    g.pos = pos; g.dir = dir;
+    g.pos = to_f(pos0); g.dir = dir;
     const float d1 = fabsf(dir.x) + fabsf(dir.y) + fabsf(dir.z);
-    g.pe0 = 2.5e-7f * (fabsf(pos.x) + fabsf(pos.y) + fabsf(pos.z));
+    g.pe0 = 2.5e-7f * (fabsf(g.pos.x) + fabsf(g.pos.y) + fabsf(g.pos.z));
     g.pe1 = 2.5e-7f * d1;
     g.sn = M.sigma / (M.iso3d ? M.norm3d_iso : M.norm3d_world);
     return g;
@@ -400,7 +415,7 @@ GPIS_DEV GuideRay guide_ray(const DevModel &M, const GuideField &F, V3 pos, V3 d
 GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRay &gr, double t)
 {
     typedef const float __attribute__((address_space(1))) *gfloat_p;
-    const float tf = (float)t;
+    const float tf = (float)(t - (double)gr.t0);
     const float tx = __builtin_fmaf(tf, gr.bx, gr.ax), ty = __builtin_fmaf(tf, gr.by, gr.ay), tz = __builtin_fmaf(tf, gr.bz, gr.az);
     const float fx0 = floorf(tx), fy0 = floorf(ty), fz0 = floorf(tz);
     // v_cvt_i32_f32 saturates and maps NaN to 0 (then the comparisons below fail and no sign is certified)
@@ -473,7 +488,7 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
     GuideRay gr;
     {
         const Frame coord = ray_frame();
-        gr = guide_ray(M, F, pos, dir, coord);
+        gr = guide_ray(M, F, pos, dir, coord, nearT);
     }
     int phase = G_INIT;
     bool early_ok = false;
@@ -748,7 +763,7 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC_TR) k_guided_transm
 // Self-check (test surface): for n query points — taken in coherent groups of 64 — evaluates the exact
 // noise3D sum and the guide, and counts violations of |N_ref - G| <= Err.  stats[0] = points checked,
 // stats[1] = violations, stats[2] = bits of max(|N_ref - G| / Err), stats[3] = bits of the mean Err.
-__global__ void __launch_bounds__(kFastBlock) k_guide_selfcheck(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+GPIS_TU_KERNEL __global__ void __launch_bounds__(kFastBlock) k_guide_selfcheck(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
                                                                const float *__restrict__ points3, unsigned long long *stats, float *ratio_max, float *err_sum)
 {
     __shared__ FastLds lds;
@@ -794,7 +809,7 @@ __global__ void __launch_bounds__(kFastBlock) k_guide_selfcheck(const DevModel *
 // (t = nearT + (k + u)*step, SCNM.cpp:129-132), and wherever the guide certifies a sign compares it
 // with the sign of the exact evaluateValue at the same t.  stats[0] = certified steps, stats[1] =
 // certified steps whose exact sign differs (must stay 0).
-__global__ void __launch_bounds__(kFastBlock) k_guide_raycheck(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
+GPIS_TU_KERNEL __global__ void __launch_bounds__(kFastBlock) k_guide_raycheck(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t n,
                                                               const gpis_ray_in *__restrict__ rays, uint32_t steps, unsigned long long *stats)
 {
     __shared__ FastLds lds;
@@ -815,7 +830,7 @@ __global__ void __launch_bounds__(kFastBlock) k_guide_raycheck(const DevModel *_
     Frame coord{};
     if (M.iso3d)
         coord = frame_from_normal(normalized(spec_3d::cov_pos_w2l(M, dir, 1.0f)));
-    const GuideRay gr = guide_ray(M, F, pos, dir, coord);
+    const GuideRay gr = guide_ray(M, F, pos, dir, coord, nearT);
     double t = (double)(nearT + step_size * u);
     unsigned long long certified = 0, bad = 0;
     uint32_t n_eval = 0;
@@ -883,10 +898,10 @@ inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTab
     const size_t per_launch = (size_t)1 << 22;   // slabs of 4 Mi blocks
     for (size_t b0 = 0; b0 < nblk; b0 += per_launch) {
         const size_t nb = nblk - b0 < per_launch ? nblk - b0 : per_launch;
-        k_guide_build<<<(unsigned)nb, 64>>>(d_model, T, *F, b0);
+        k_guide_build<0><<<(unsigned)nb, 64>>>(d_model, T, *F, b0);
     }
     for (size_t b0 = 0; b0 < nblk; b0 += (size_t)1 << 30)     // second pass: the blocks' bounds on |N| (reads every sample of the field)
-        k_guide_amax<<<(unsigned)(((nblk - b0 < ((size_t)1 << 30) ? nblk - b0 : ((size_t)1 << 30)) + 255) / 256), 256>>>(*F, b0, nblk);
+        k_guide_amax<0><<<(unsigned)(((nblk - b0 < ((size_t)1 << 30) ? nblk - b0 : ((size_t)1 << 30)) + 255) / 256), 256>>>(*F, b0, nblk);
     if (hipDeviceSynchronize() != hipSuccess) { guide_free(F); return GPIS_ERR_DEVICE; }
     F->enabled = 1;
     return GPIS_OK;

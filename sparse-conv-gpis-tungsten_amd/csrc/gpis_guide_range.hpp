@@ -173,7 +173,7 @@ GPIS_DEV void guided_march_range(const DevModel &M, const FastTable &T, const Gu
                             step_size = M.step_size;
                         {
                             const Frame coord = ray_frame();
-                            gr = guide_ray(M, F, pos, dir, coord);
+                            gr = guide_ray(M, F, pos, dir, coord, nearT);
                         }
                         early_ok = false; bounce_stop = false;
                         t = (double)nearT; t_prevpos = (double)nearT;

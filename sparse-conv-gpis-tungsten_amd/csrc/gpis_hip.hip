@@ -22,15 +22,16 @@
 
 #include "gpis.h"
 #include "gpis_device.hpp"
-#include "gpis_fast.hpp"
-#include "gpis_guide.hpp"
-#include "gpis_guide_range.hpp"
-#include "gpis_wave.hpp"
-#include "gpis_fs.hpp"
+#include "gpis_fast.hpp"      // FastTable, fast_supported (no kernel of it is instantiated here)
+#include "gpis_guide.hpp"     // GuideField, guide_free
+#include "gpis_launch.hpp"    // the march kernels live in the tu_*.hip translation units
 
 #pragma clang fp contract(off)
 
 using namespace gpis;
+using gpis::launch::grid_of;
+constexpr int kBlock = 64;   // one wave per workgroup (gpis_lane.hpp)
+constexpr unsigned kPersistSlots = 256;   // ring of ray counters: one per persistent launch in flight
 
 // ======================================================================================
 // errors
@@ -389,161 +390,6 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
     return GPIS_OK;
 }
 
-namespace gpis {
-hipError_t sort_pairs_u32(void *temp, size_t &temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                          const uint32_t *vals_in, uint32_t *vals_out, size_t n, hipStream_t stream);   // gpis_sort.hip
-}
-
-// ======================================================================================
-// kernels — generic path: one lane = one ray / query, impulses generated on the fly
-// ======================================================================================
-constexpr int kBlock = 64;   // one wave per workgroup: rays are independent, small blocks balance the march
-#ifndef GPIS_GENERIC_OCC
-#define GPIS_GENERIC_OCC 4   // waves per SIMD the lane-per-ray march kernels are register-allocated for (C2 scene S: 1 wave 11.6, 2 → 20.4, 3 → 25.2, 4 → 26.6, 5 → 26.0 Msamples/s)
-#endif
-
-__device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t n_eval, uint32_t n_seg)
-{
-    // one pair of 64-bit atomics per wave
-    unsigned long long e = n_eval, s = n_seg;
-    for (int off = 32; off > 0; off >>= 1) {
-        e += __shfl_down(e, off, 64);
-        s += __shfl_down(s, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (e) atomicAdd(&cnt->n_eval, e);
-        if (s) atomicAdd(&cnt->n_seg, s);
-    }
-}
-
-// P = the path instance (gpis_device.hpp: generic / spec_1d / spec_3d / spec_3d_multires)
-template <class P>
-__global__ void __launch_bounds__(kBlock, GPIS_GENERIC_OCC) k_sample_distance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
-                                                            gpis_seg_out *__restrict__ out, gpis_cond_coeff *__restrict__ coeff,
-                                                            const uint8_t *__restrict__ mask, Counters *cnt)
-{
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const DevModel &M = *Mp;
-    Realization noise{};
-    uint32_t nseg = 0;
-    if (i < n && (!mask || mask[i])) {
-        gpis_ray_in ray = rays[i];
-        gpis_seg_out o;
-        P::sample_distance(M, noise, ray, o);
-        out[i] = o;
-        if (coeff) {
-            gpis_cond_coeff c = noise.c;
-            c.n_evals = noise.n_eval;
-            coeff[i] = c;
-        }
-        nseg = 1;
-    }
-    flush_counters(cnt, noise.n_eval, nseg);
-}
-
-template <class P>
-__global__ void __launch_bounds__(kBlock, GPIS_GENERIC_OCC) k_transmittance(const DevModel *__restrict__ Mp, size_t n, const gpis_ray_in *__restrict__ rays,
-                                                          uint8_t *__restrict__ visible, const uint8_t *__restrict__ mask, Counters *cnt)
-{
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const DevModel &M = *Mp;
-    Realization noise{};
-    uint32_t nseg = 0;
-    if (i < n) {
-        if (!mask || mask[i]) {
-            gpis_ray_in ray = rays[i];
-            MediumState st;
-            state_from_ray(ray, st);
-            visible[i] = P::transmittance(M, noise, ray, st) ? 1 : 0;
-            nseg = 1;
-        } else {
-            visible[i] = 0;
-        }
-    }
-    flush_counters(cnt, noise.n_eval, nseg);
-}
-
-// persistent refilling form of the two kernels above (gpis_persist.inc): a fixed grid of waves pulls rays from
-// a counter.  Q = slots of the per-lane LDS queue between the impulse generator and the kernel body.
-#ifndef GPIS_PERSIST_Q
-#define GPIS_PERSIST_Q 16
-#endif
-constexpr int kPersistQ = GPIS_PERSIST_Q;
-constexpr unsigned kPersistSlots = 256;   // ring of ray counters: one per persistent launch in flight
-#ifndef GPIS_PERSIST_OCC
-#define GPIS_PERSIST_OCC 3   // waves per SIMD of the register allocation (LDS: 12.5 KB per wave -> 12 waves per CU)
-#endif
-template <class P, bool WANT_SAMPLE>
-__global__ void __launch_bounds__(kBlock, GPIS_PERSIST_OCC) k_persist_march(const DevModel *__restrict__ Mp, PersistArgs a)
-{
-    __shared__ PersistQueue<kPersistQ> q;
-    fast_lds_init(q);
-    P::template march<WANT_SAMPLE, kPersistQ>(*Mp, a, q);
-}
-
-__device__ __forceinline__ RayInfo info_of(const gpis_query &q) { return RayInfo{q.pixel[0], q.pixel[1], q.spp, q.segment, q.scene_seed, q.info_t}; }
-__device__ __forceinline__ RayInfo info_of(const gpis_nee_query &q) { return RayInfo{q.pixel[0], q.pixel[1], q.spp, q.segment, q.scene_seed, q.info_t}; }
-
-__global__ void __launch_bounds__(kBlock) k_eval_value(const DevModel *__restrict__ Mp, size_t n, const gpis_query *__restrict__ q,
-                                                       float *__restrict__ value, int32_t *__restrict__ gp_id, Counters *cnt)
-{
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    Realization r{};
-    if (i < n) {
-        gpis_query qq = q[i];
-        r.c = qq.coeff;
-        int id;
-        value[i] = generic::evaluate_value(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq), id);
-        if (gp_id) gp_id[i] = id;
-    }
-    flush_counters(cnt, r.n_eval, 0);
-}
-__global__ void __launch_bounds__(kBlock) k_eval_gradient(const DevModel *__restrict__ Mp, size_t n, const gpis_query *__restrict__ q,
-                                                          float *__restrict__ grad3, Counters *cnt)
-{
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    Realization r{};
-    if (i < n) {
-        gpis_query qq = q[i];
-        r.c = qq.coeff;
-        V3 g = generic::evaluate_gradient(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), qq.t_segment, v3(qq.dir[0], qq.dir[1], qq.dir[2]), info_of(qq));
-        grad3[3 * i] = g.x; grad3[3 * i + 1] = g.y; grad3[3 * i + 2] = g.z;
-    }
-    flush_counters(cnt, r.n_eval, 0);
-}
-__global__ void __launch_bounds__(kBlock) k_conditioning(const DevModel *__restrict__ Mp, size_t n, const gpis_query *__restrict__ q,
-                                                         const float *__restrict__ tv, const float *__restrict__ tg,
-                                                         gpis_cond_coeff *__restrict__ co, Counters *cnt)
-{
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    Realization r{};
-    if (i < n) {
-        gpis_query qq = q[i];
-        generic::conditioning(*Mp, r, v3(qq.p[0], qq.p[1], qq.p[2]), v3(qq.dir[0], qq.dir[1], qq.dir[2]), tv[i], v3(tg[3 * i], tg[3 * i + 1], tg[3 * i + 2]), info_of(qq));
-        gpis_cond_coeff c = r.c;
-        c.n_evals = r.n_eval;
-        co[i] = c;
-    }
-    flush_counters(cnt, r.n_eval, 0);
-}
-__global__ void __launch_bounds__(kBlock) k_nee(const DevModel *__restrict__ Mp, size_t n, const gpis_nee_query *__restrict__ q,
-                                                float *__restrict__ pdf, float *__restrict__ grad3, Counters *cnt,
-                                                const uint8_t *__restrict__ mask = nullptr)
-{
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    Realization r{};
-    if (i < n && (!mask || mask[i])) {
-        gpis_nee_query qq = q[i];
-        r.c = qq.coeff;
-        V3 rd = v3(qq.ray_dir[0], qq.ray_dir[1], qq.ray_dir[2]), nn = v3(qq.normal[0], qq.normal[1], qq.normal[2]), p = v3(qq.p[0], qq.p[1], qq.p[2]);
-        if (pdf) pdf[i] = generic::nee_pdf(*Mp, r, rd, nn, p, qq.t_segment, info_of(qq));
-        if (grad3) {
-            V3 g = generic::nee_grad(*Mp, r, rd, nn, p, info_of(qq));
-            grad3[3 * i] = g.x; grad3[3 * i + 1] = g.y; grad3[3 * i + 2] = g.z;
-        }
-    }
-    flush_counters(cnt, r.n_eval, 0);
-}
 // MeanFunction::color / emission at double-precision points (GPF.hpp:849-857; ramp noises: three equal components)
 __global__ void __launch_bounds__(256) k_mean_color_emission(const DevModel *__restrict__ Mp, size_t n, const double *__restrict__ p3,
                                                              float *__restrict__ color3, float *__restrict__ emission3)
@@ -1108,7 +954,6 @@ __global__ void __launch_bounds__(256) k_nee_gather(float cap_radiance, size_t n
 // ======================================================================================
 // C ABI
 // ======================================================================================
-static inline unsigned grid_of(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 extern "C" const char *gpis_abi_sizes(void)
 {
@@ -1240,7 +1085,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         delete m;
         return GPIS_ERR_DEVICE;
     }
-    st = fast_table_build(m->host_model, m->d_model, &m->fast);
+    st = launch::fast_table_build(m->host_model, &m->fast);
     if (st != GPIS_OK) {
         set_err(st, "gpis_create: building the cell table failed");
         (void)hipFree(m->d_model); (void)hipFree(m->d_counters); (void)hipFree(m->d_guide_cnt); (void)hipFree(m->d_guide); (void)hipFree(m->d_next);
@@ -1363,15 +1208,16 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
         return set_err(GPIS_ERR_DEVICE, "radix sort scratch query failed");
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_cnt = carve(64), o_state = carve(n * sizeof(WaveState)), o_k0 = carve(n * 4), o_v0 = carve(n * 4), o_k1 = carve(n * 4),
+    const size_t o_cnt = carve(64), o_state = carve(n * launch::wave_state_bytes()), o_k0 = carve(n * 4), o_v0 = carve(n * 4), o_k1 = carve(n * 4),
                  o_v1 = carve(n * 4), o_temp = carve(temp_bytes);
     int rc = ensure_stage(m, 4, off);
     if (rc) return rc;
     if ((rc = ws_acquire(m, 1, s))) return rc;
     char *ws = (char *)m->stage[4];
     unsigned long long *d_req = (unsigned long long *)(ws + o_cnt);
-    WaveState *state = (WaveState *)(ws + o_state);
     uint32_t *k0 = (uint32_t *)(ws + o_k0), *v0 = (uint32_t *)(ws + o_v0), *k1 = (uint32_t *)(ws + o_k1), *v1 = (uint32_t *)(ws + o_v1);
+    const launch::WaveBufs wb{ws + o_state, k0, v0, k1, v1, d_req};
+    const bool small_arg = m->host_model.exp_arg_max < 100.f;
     Counters *cnt = m->d_counters + (want_sample ? 0 : 1);
     auto read_requests = [&](size_t &n_req) -> int {
         unsigned long long h = 0;
@@ -1387,10 +1233,7 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
     const uint32_t *active = nullptr;
     int init = 1;
     for (;;) {
-        if (want_sample)
-            k_wave_step<true><<<grid_of(n_active, 256), 256, 0, s>>>(m->d_model, m->guide, n_active, active, init, rays, mask, state, k0, v0, d_req, m->d_guide_cnt);
-        else
-            k_wave_step<false><<<grid_of(n_active, 256), 256, 0, s>>>(m->d_model, m->guide, n_active, active, init, rays, mask, state, k0, v0, d_req, m->d_guide_cnt);
+        launch::wave_step(want_sample, m->d_model, m->guide, n_active, active, init, rays, mask, wb, m->d_guide_cnt, s);
         if ((rc = launch_check("k_wave_step"))) return rc;
         size_t n_req = 0;
         if ((rc = read_requests(n_req))) return rc;
@@ -1399,26 +1242,20 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
         size_t tb = temp_bytes;
         if (sort_pairs_u32(ws + o_temp, tb, k0, k1, v0, v1, n_active, s) != hipSuccess)
             return set_err(GPIS_ERR_DEVICE, "radix sort failed");
-        if (m->host_model.exp_arg_max < 100.f)
-            k_wave_eval<true><<<grid_of(n_req, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_req, v1, rays, state, cnt);
-        else
-            k_wave_eval<false><<<grid_of(n_req, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_req, v1, rays, state, cnt);
+        launch::wave_eval(small_arg, m->d_model, m->fast, m->guide, n_req, v1, rays, wb, cnt, s);
         if ((rc = launch_check("k_wave_eval"))) return rc;
         active = v1;            // the sorted requesters are the rays still marching
         n_active = n_req;
         init = 0;
         if (n_active <= tail_limit) {
             // few rays left: one wave per ray runs them to the end of their value requests
-            if (want_sample)
-                k_wave_tail<true><<<(unsigned)n_active, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_active, active, rays, state, cnt, m->d_guide_cnt);
-            else
-                k_wave_tail<false><<<(unsigned)n_active, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_active, active, rays, state, cnt, m->d_guide_cnt);
+            launch::wave_tail(want_sample, m->d_model, m->fast, m->guide, n_active, active, rays, wb, cnt, m->d_guide_cnt, s);
             if ((rc = launch_check("k_wave_tail"))) return rc;
             break;
         }
     }
     if (want_sample) {
-        k_wave_grad_keys<<<grid_of(n, 256), 256, 0, s>>>(m->d_model, m->guide, n, rays, state, k0, v0, d_req);
+        launch::wave_grad_keys(m->d_model, m->guide, n, rays, wb, s);
         if ((rc = launch_check("k_wave_grad_keys"))) return rc;
         size_t n_grad = 0;
         if ((rc = read_requests(n_grad))) return rc;
@@ -1426,17 +1263,14 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
             size_t tb = temp_bytes;
             if (sort_pairs_u32(ws + o_temp, tb, k0, k1, v0, v1, n, s) != hipSuccess)
                 return set_err(GPIS_ERR_DEVICE, "radix sort failed");
-            if (m->host_model.exp_arg_max < 100.f)
-                k_wave_grad<true><<<grid_of(n_grad, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_grad, v1, rays, state, cnt);
-            else
-                k_wave_grad<false><<<grid_of(n_grad, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n_grad, v1, rays, state, cnt);
+            launch::wave_grad(small_arg, m->d_model, m->fast, m->guide, n_grad, v1, rays, wb, cnt, s);
             if ((rc = launch_check("k_wave_grad"))) return rc;
         }
-        k_wave_finish_sd<<<grid_of(n, 256), 256, 0, s>>>(m->d_model, n, rays, mask, state, out, coeff, cnt);
+        launch::wave_finish_sd(m->d_model, n, rays, mask, wb, out, coeff, cnt, s);
         if ((rc = launch_check("k_wave_finish_sd"))) return rc;
         return ws_release(m, 1, s);
     }
-    k_wave_finish_tr<<<grid_of(n, 256), 256, 0, s>>>(n, mask, state, visible, cnt);
+    launch::wave_finish_tr(n, mask, wb, visible, cnt, s);
     if ((rc = launch_check("k_wave_finish_tr"))) return rc;
     return ws_release(m, 1, s);
 }
@@ -1456,38 +1290,37 @@ static int persist_solo_max(const gpis_medium *m)
     int t = (int)(lock / side);
     return t < 0 ? 0 : (t > 48 ? 48 : t);
 }
-template <class P, bool WANT_SAMPLE>
-static int launch_persist_t(gpis_medium *m, int slot_id, PersistArgs a, hipStream_t s)
-{
-    auto kern = k_persist_march<P, WANT_SAMPLE>;
-    if (m->persist_waves[slot_id] == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kBlock, 0) != hipSuccess || nb <= 0) { (void)hipGetLastError(); nb = 8; }
-        m->persist_waves[slot_id] = nb * m->n_cus;
-    }
-    const size_t waves_needed = (a.n + kBlock - 1) / kBlock;
-    const unsigned grid = (unsigned)(waves_needed < (size_t)m->persist_waves[slot_id] ? waves_needed : (size_t)m->persist_waves[slot_id]);
-    a.next = m->d_next + (m->next_slot++ % kPersistSlots);
-    HIP_TRY(hipMemsetAsync(a.next, 0, sizeof(unsigned int), s));
-    kern<<<grid, kBlock, 0, s>>>(m->d_model, a);
-    return launch_check("k_persist_march");
-}
 template <bool WANT_SAMPLE>
 static int launch_persist(gpis_medium *m, PersistArgs a, hipStream_t s)
 {
     const DevModel &H = m->host_model;
     if (a.n >= 0xFFFF0000ull) return set_err(GPIS_ERR_INVALID_ARG, "persistent march: batch too large for the 32-bit ray counter");
     a.solo_max = persist_solo_max(m);
-    const int w = WANT_SAMPLE ? 0 : 4;
-    if (H.sampling_1d)
-        return launch_persist_t<spec_1d::Persist, WANT_SAMPLE>(m, w + 0, a, s);
-    if (H.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
-        return launch_persist_t<generic::Persist, WANT_SAMPLE>(m, w + 3, a, s);
-    if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid)
-        return launch_persist_t<spec_3d::Persist, WANT_SAMPLE>(m, w + 1, a, s);
-    if (H.nonstationary && H.multi_res && H.multi_resolution_grid)
-        return launch_persist_t<spec_3d_multires::Persist, WANT_SAMPLE>(m, w + 2, a, s);
-    return launch_persist_t<generic::Persist, WANT_SAMPLE>(m, w + 3, a, s);
+    int inst = launch::INST_GENERIC;
+    if (H.sampling_1d) inst = launch::INST_1D;
+    else if (H.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) inst = launch::INST_GENERIC;
+    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid) inst = launch::INST_3D;
+    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid) inst = launch::INST_3D_MULTIRES;
+    const int slot_id = (WANT_SAMPLE ? 0 : 4) + inst;
+    if (m->persist_waves[slot_id] == 0) {
+        int nb = launch::persist_blocks_per_cu(inst, WANT_SAMPLE);
+        if (nb <= 0) nb = 8;
+        m->persist_waves[slot_id] = nb * m->n_cus;
+    }
+    const size_t waves_needed = (a.n + kBlock - 1) / kBlock;
+    const unsigned grid = (unsigned)(waves_needed < (size_t)m->persist_waves[slot_id] ? waves_needed : (size_t)m->persist_waves[slot_id]);
+    a.next = m->d_next + (m->next_slot++ % kPersistSlots);
+    HIP_TRY(hipMemsetAsync(a.next, 0, sizeof(unsigned int), s));
+    launch::persist_march(inst, WANT_SAMPLE, grid, m->d_model, a, s);
+    return launch_check("k_persist_march");
+}
+// the lane-per-ray instance whose compile-time flags equal the medium's
+static int lane_instance(const DevModel &H)
+{
+    if (H.sampling_1d) return launch::INST_1D;
+    if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL) return launch::INST_3D;
+    if (H.nonstationary && H.multi_res && H.multi_resolution_grid && !H.aniso.enabled) return launch::INST_3D_MULTIRES;
+    return launch::INST_GENERIC;
 }
 
 static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff,
@@ -1499,29 +1332,16 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
         return wave_march(m, n, rays, mask, true, out, coeff, nullptr, s);
     if (m->guide.enabled && m->opt[GPIS_OPT_RANGE_LEN] > 0) {
         // guided march with in-wave refill (gpis_guide_range.hpp) + one coherent gradient pass
-        RangeArgs a{};
-        a.n = n; a.rays = rays; a.out = out; a.coeff = coeff; a.visible = nullptr; a.mask = mask; a.cnt = m->d_counters; a.guide_cnt = m->d_guide_cnt;
-        a.range_len = (uint32_t)m->opt[GPIS_OPT_RANGE_LEN];
-        const unsigned grid = (unsigned)((n + a.range_len - 1) / a.range_len);
-        const bool small = m->host_model.exp_arg_max < 100.f;
-        if (small) k_guided_range_sd<true><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
-        else k_guided_range_sd<false><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
-        int rc = launch_check("k_guided_range_sd");
-        if (rc) return rc;
-        if (small) k_guided_range_grad<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters);
-        else k_guided_range_grad<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters);
-        return launch_check("k_guided_range_grad");
+        launch::range_sample_distance(m->host_model.exp_arg_max < 100.f, m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt,
+                                      (uint32_t)m->opt[GPIS_OPT_RANGE_LEN], s);
+        return launch_check("k_guided_range_sd / k_guided_range_grad");
     }
     if (m->guide.enabled) {
-        if (m->host_model.exp_arg_max < 100.f)
-            k_guided_sample_distance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
-        else
-            k_guided_sample_distance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt);
+        launch::guided_sample_distance(m->host_model.exp_arg_max < 100.f, m->d_model, m->fast, m->d_guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt, s);
         return launch_check("k_guided_sample_distance");
     }
     if (m->fast.enabled) {
-        int st = fast_sample_distance(m->d_model, &m->fast, n, rays, out, coeff, mask, m->d_counters, s);
-        if (st != GPIS_OK) return set_err(st, "fast sample_distance launch failed");
+        launch::fast_sample_distance(m->d_model, m->fast, n, rays, out, coeff, mask, m->d_counters, s);
         return launch_check("k_fast_sample_distance");
     }
     // pick the instance whose compile-time flags equal the medium's
@@ -1531,15 +1351,7 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
         a.n = n; a.rays = rays; a.out = out; a.coeff = coeff; a.visible = nullptr; a.mask = mask; a.cnt = m->d_counters;
         return launch_persist<true>(m, a, s);
     }
-    const unsigned grid = grid_of(n, kBlock);
-    if (H.sampling_1d)
-        k_sample_distance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
-    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL)
-        k_sample_distance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
-    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid && !H.aniso.enabled)
-        k_sample_distance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
-    else
-        k_sample_distance<generic::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, out, coeff, mask, m->d_counters);
+    launch::lane_sample_distance(lane_instance(H), m->d_model, n, rays, out, coeff, mask, m->d_counters, s);
     return launch_check("k_sample_distance");
 }
 static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays, uint8_t *visible, const uint8_t *mask, hipStream_t s,
@@ -1550,24 +1362,16 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
     if (m->guide.enabled && wave_march_selected(m, hint))
         return wave_march(m, n, rays, mask, false, nullptr, nullptr, visible, s);
     if (m->guide.enabled && m->opt[GPIS_OPT_RANGE_LEN] > 0) {
-        RangeArgs a{};
-        a.n = n; a.rays = rays; a.out = nullptr; a.coeff = nullptr; a.visible = visible; a.mask = mask; a.cnt = m->d_counters + 1; a.guide_cnt = m->d_guide_cnt;
-        a.range_len = (uint32_t)m->opt[GPIS_OPT_RANGE_LEN];
-        const unsigned grid = (unsigned)((n + a.range_len - 1) / a.range_len);
-        if (m->host_model.exp_arg_max < 100.f) k_guided_range_tr<true><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
-        else k_guided_range_tr<false><<<grid, kFastBlock, 0, s>>>(m->d_model, m->fast, m->guide, a);
+        launch::range_transmittance(m->host_model.exp_arg_max < 100.f, m->d_model, m->fast, m->guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt,
+                                    (uint32_t)m->opt[GPIS_OPT_RANGE_LEN], s);
         return launch_check("k_guided_range_tr");
     }
     if (m->guide.enabled) {
-        if (m->host_model.exp_arg_max < 100.f)
-            k_guided_transmittance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
-        else
-            k_guided_transmittance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(m->d_model, m->fast, m->d_guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt);
+        launch::guided_transmittance(m->host_model.exp_arg_max < 100.f, m->d_model, m->fast, m->d_guide, n, rays, visible, mask, m->d_counters + 1, m->d_guide_cnt, s);
         return launch_check("k_guided_transmittance");
     }
     if (m->fast.enabled) {
-        int st = fast_transmittance(m->d_model, &m->fast, n, rays, visible, mask, m->d_counters + 1, s);
-        if (st != GPIS_OK) return set_err(st, "fast transmittance launch failed");
+        launch::fast_transmittance(m->d_model, m->fast, n, rays, visible, mask, m->d_counters + 1, s);
         return launch_check("k_fast_transmittance");
     }
     const DevModel &H = m->host_model;
@@ -1576,15 +1380,7 @@ static int transmittance_impl(gpis_medium *m, size_t n, const gpis_ray_in *rays,
         a.n = n; a.rays = rays; a.out = nullptr; a.coeff = nullptr; a.visible = visible; a.mask = mask; a.cnt = m->d_counters + 1;
         return launch_persist<false>(m, a, s);
     }
-    const unsigned grid = grid_of(n, kBlock);
-    if (H.sampling_1d)
-        k_transmittance<spec_1d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
-    else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL)
-        k_transmittance<spec_3d::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
-    else if (H.nonstationary && H.multi_res && H.multi_resolution_grid && !H.aniso.enabled)
-        k_transmittance<spec_3d_multires::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
-    else
-        k_transmittance<generic::Path><<<grid, kBlock, 0, s>>>(m->d_model, n, rays, visible, mask, m->d_counters + 1);
+    launch::lane_transmittance(lane_instance(H), m->d_model, n, rays, visible, mask, m->d_counters + 1, s);
     return launch_check("k_transmittance");
 }
 
@@ -1637,7 +1433,7 @@ extern "C" int gpis_eval_value_batch(gpis_medium *m, size_t n, const gpis_query 
     CHECK_ARGS(m && (n == 0 || (q && value)));
     if (n == 0) return GPIS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    k_eval_value<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, value, gp_id, m->d_counters);
+    launch::eval_value(m->d_model, n, q, value, gp_id, m->d_counters, (hipStream_t)stream);
     return launch_check("k_eval_value");
 }
 extern "C" int gpis_eval_gradient_batch(gpis_medium *m, size_t n, const gpis_query *q, float *grad3, void *stream)
@@ -1645,7 +1441,7 @@ extern "C" int gpis_eval_gradient_batch(gpis_medium *m, size_t n, const gpis_que
     CHECK_ARGS(m && (n == 0 || (q && grad3)));
     if (n == 0) return GPIS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    k_eval_gradient<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, grad3, m->d_counters);
+    launch::eval_gradient(m->d_model, n, q, grad3, m->d_counters, (hipStream_t)stream);
     return launch_check("k_eval_gradient");
 }
 extern "C" int gpis_conditioning_batch(gpis_medium *m, size_t n, const gpis_query *q, const float *target_val, const float *target_grad3,
@@ -1654,7 +1450,7 @@ extern "C" int gpis_conditioning_batch(gpis_medium *m, size_t n, const gpis_quer
     CHECK_ARGS(m && (n == 0 || (q && target_val && target_grad3 && coeff_out)));
     if (n == 0) return GPIS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    k_conditioning<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, target_val, target_grad3, coeff_out, m->d_counters);
+    launch::conditioning(m->d_model, n, q, target_val, target_grad3, coeff_out, m->d_counters, (hipStream_t)stream);
     return launch_check("k_conditioning");
 }
 extern "C" int gpis_nee_pdf_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *pdf, void *stream)
@@ -1662,7 +1458,7 @@ extern "C" int gpis_nee_pdf_batch(gpis_medium *m, size_t n, const gpis_nee_query
     CHECK_ARGS(m && (n == 0 || (q && pdf)));
     if (n == 0) return GPIS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    k_nee<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, pdf, nullptr, m->d_counters);
+    launch::nee(m->d_model, n, q, pdf, nullptr, m->d_counters, nullptr, (hipStream_t)stream);
     return launch_check("k_nee");
 }
 extern "C" int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *grad3, void *stream)
@@ -1670,7 +1466,7 @@ extern "C" int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_quer
     CHECK_ARGS(m && (n == 0 || (q && grad3)));
     if (n == 0) return GPIS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    k_nee<<<grid_of(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(m->d_model, n, q, nullptr, grad3, m->d_counters);
+    launch::nee(m->d_model, n, q, nullptr, grad3, m->d_counters, nullptr, (hipStream_t)stream);
     return launch_check("k_nee");
 }
 extern "C" int gpis_mean_color_emission_batch(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3, void *stream)
@@ -1690,8 +1486,7 @@ static int fs_check(gpis_medium *m)
         return set_err(GPIS_ERR_INVALID_ARG, "function-space path: squared-exponential covariance, analytic mean, 2..64 sample points");
     return GPIS_OK;
 }
-template <bool WANT_SAMPLE>
-static int fs_launch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, uint8_t *visible, hipStream_t s)
+static int fs_launch(bool want_sample, gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, uint8_t *visible, hipStream_t s)
 {
     HIP_TRY(hipSetDevice(m->device));
     // 37 KB of LDS per workgroup: four one-wave workgroups (one per SIMD) are resident per CU and walk the batch
@@ -1700,35 +1495,30 @@ static int fs_launch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_
         std::lock_guard<std::mutex> lock(m->mu);
         if (m->fs_ws_blocks < cap) {
             if (m->fs_ws) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(m->fs_ws); m->fs_ws = nullptr; m->fs_ws_blocks = 0; }
-            if (hipMalloc(&m->fs_ws, (size_t)cap * sizeof(FsGlob)) != hipSuccess) { (void)hipGetLastError(); return set_err(GPIS_ERR_DEVICE, "function-space workspace allocation failed"); }
+            if (hipMalloc(&m->fs_ws, (size_t)cap * launch::fs_workspace_bytes_per_block()) != hipSuccess) { (void)hipGetLastError(); return set_err(GPIS_ERR_DEVICE, "function-space workspace allocation failed"); }
             m->fs_ws_blocks = cap;
         }
     }
     const unsigned grid = (unsigned)(n < cap ? n : cap);
-    k_fs_march<WANT_SAMPLE><<<grid, 64, 0, s>>>(m->d_model, n, rays, states, out, visible, (FsGlob *)m->fs_ws);
+    launch::fs_march(want_sample, grid, m->d_model, n, rays, states, out, visible, m->fs_ws, s);
     return launch_check("k_fs_march");
 }
 #ifdef GPIS_FS_PROF
-extern "C" int gpis_fs_prof_read(unsigned long long *out16, int reset)
-{
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpis::g_fs_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return GPIS_ERR_DEVICE;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gpis::g_fs_prof), z, sizeof z) != hipSuccess) return GPIS_ERR_DEVICE; }
-    return GPIS_OK;
-}
+extern "C" int gpis_fs_prof_read(unsigned long long *out16, int reset) { return launch::fs_prof_read(out16, reset); }
 #endif
 extern "C" int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && states && out)));
     if (int st = fs_check(m)) return st;
     if (n == 0) return GPIS_OK;
-    return fs_launch<true>(m, n, rays, states, out, nullptr, (hipStream_t)stream);
+    return fs_launch(true, m, n, rays, states, out, nullptr, (hipStream_t)stream);
 }
 extern "C" int gpis_fs_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && states && visible)));
     if (int st = fs_check(m)) return st;
     if (n == 0) return GPIS_OK;
-    return fs_launch<false>(m, n, rays, states, nullptr, visible, (hipStream_t)stream);
+    return fs_launch(false, m, n, rays, states, nullptr, visible, (hipStream_t)stream);
 }
 extern "C" int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3)
 {
@@ -1981,7 +1771,7 @@ extern "C" int gpis_build_guide(gpis_medium *m, int half_extent_cells, int point
     HIP_TRY(hipDeviceSynchronize());
     if (!m->fast.enabled)
         return set_err(GPIS_ERR_UNSUPPORTED, "gpis_build_guide: the medium is not covered by the wave-cooperative path (single_realization, 3D, stationary SE, diagonal anisotropy)");
-    int st = guide_build(m->host_model, m->d_model, m->fast, half_extent_cells, points_per_cell, &m->guide);
+    int st = launch::guide_build(m->host_model, m->d_model, m->fast, half_extent_cells, points_per_cell, &m->guide);
     if (st != GPIS_OK)
         return set_err(st, "gpis_build_guide(half=%d, ppc=%d) failed: %s", half_extent_cells, points_per_cell,
                        st == GPIS_ERR_UNSUPPORTED ? "unsupported arguments" : hipGetErrorString(hipGetLastError()));
@@ -2018,7 +1808,7 @@ extern "C" int gpis_guide_selfcheck(gpis_medium *m, size_t n, const float *point
     unsigned long long *st = m->d_guide_cnt + 1;
     HIP_TRY(hipMemsetAsync(st, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
     if (n)
-        k_guide_selfcheck<<<grid_of(n, kFastBlock), kFastBlock, 0, (hipStream_t)stream>>>(m->d_model, m->fast, m->guide, n, points3, st, (float *)(st + 2), (float *)(st + 2) + 1);
+        launch::guide_selfcheck(m->d_model, m->fast, m->guide, n, points3, st, (float *)(st + 2), (float *)(st + 2) + 1, (hipStream_t)stream);
     int rc = launch_check("k_guide_selfcheck");
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -2042,7 +1832,7 @@ extern "C" int gpis_guide_raycheck(gpis_medium *m, size_t n, const gpis_ray_in *
     unsigned long long *st = m->d_guide_cnt + 1;
     HIP_TRY(hipMemsetAsync(st, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
     if (n)
-        k_guide_raycheck<<<grid_of(n, kFastBlock), kFastBlock, 0, (hipStream_t)stream>>>(m->d_model, m->fast, m->guide, n, rays, steps, st);
+        launch::guide_raycheck(m->d_model, m->fast, m->guide, n, rays, steps, st, (hipStream_t)stream);
     int rc = launch_check("k_guide_raycheck");
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -2081,15 +1871,13 @@ extern "C" int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_
 }
 
 #ifdef GPIS_FAST_STATS
-// diagnostic build only: read and clear the cooperative loop's work counters
+// diagnostic build only: read and clear the cooperative loop's work counters (of the guided sampleDistance kernel's TU)
 extern "C" int gpis_debug_fast_stats(uint64_t *out32)
 {
     unsigned long long h[32];
-    if (hipDeviceSynchronize() != hipSuccess) return GPIS_ERR_DEVICE;
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gpis::g_fast_stats), sizeof h) != hipSuccess) return GPIS_ERR_DEVICE;
+    int st = launch::fast_stats_read(h);
+    if (st != GPIS_OK) return st;
     for (int i = 0; i < 32; ++i) out32[i] = h[i];
-    memset(h, 0, sizeof h);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(gpis::g_fast_stats), h, sizeof h) != hipSuccess) return GPIS_ERR_DEVICE;
     return GPIS_OK;
 }
 #endif
@@ -2340,9 +2128,9 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
         if ((rc = sample_distance_impl(m, ns, a.rays, a.seg, b.coeff, a.alive, st))) return rc;
         k_nee_setup<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);
         if ((rc = launch_check("k_nee_setup"))) return rc;
-        k_nee<<<grid_of(ns, kBlock), kBlock, 0, st>>>(m->d_model, ns, b.q_half, b.pdf_half, b.grad_half, m->d_counters, b.want_light);
+        launch::nee(m->d_model, ns, b.q_half, b.pdf_half, b.grad_half, m->d_counters, b.want_light, st);
         if ((rc = launch_check("k_nee"))) return rc;
-        k_nee<<<grid_of(ns, kBlock), kBlock, 0, st>>>(m->d_model, ns, b.q_normal, b.pdf_normal, nullptr, m->d_counters, b.want_pdf_normal);
+        launch::nee(m->d_model, ns, b.q_normal, b.pdf_normal, nullptr, m->d_counters, b.want_pdf_normal, st);
         if ((rc = launch_check("k_nee"))) return rc;
         k_nee_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);
         if ((rc = launch_check("k_nee_shade"))) return rc;

@@ -186,7 +186,7 @@ GPIS_DEV void wave_guide_steps(const DevModel &M, const GuideField &F, const Wav
 {
     if (!(s.phase == G_INIT || s.phase == G_MARCH || s.phase == X_FINAL))
         return;
-    const GuideRay gr = guide_ray(M, F, w.pos, w.dir, wave_frame(M, w.dir));
+    const GuideRay gr = guide_ray(M, F, w.pos, w.dir, wave_frame(M, w.dir), w.nearT);
     for (;;) {
         if (!WANT_SAMPLE && s.phase == X_FINAL) {
             s.flags &= (uint8_t)~kWaveHit;      // transmittance: the segment exits, lastVal is not part of the result

@@ -50,6 +50,10 @@ def test_c1_full_frame_properties(pkg, ob):
     # plausible picture: the sphere covers the centre, radiance is bounded by spp * cos <= spp
     assert hits[H // 2, W // 2] == SPP and hits[0, 0] < SPP
     assert 0 < img.max() <= SPP and img.min() >= 0
+    # the guide resolution the headline is measured with (bench.py --guide 16:64: side 2048, 34 GB): the SAME frame, bit for bit
+    med.build_guide(16, 64)
+    img64, hits64 = _render(pkg, med, scene)
+    assert np.array_equal(img64, img) and np.array_equal(hits64, hits)
     # the exact (unguided) kernels give the same frame on a band of rows
     med.drop_guide()
     band = [(520, 32)]

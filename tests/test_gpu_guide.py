@@ -35,34 +35,86 @@ def test_guide_bound_holds(pkg, cfg, ppc):
     assert 0 < bound < 50
 
 
-@pytest.mark.parametrize("cfg,half,ppc", [("C1", 16, 32), ("C0", 16, 16), ("C1", 6, 8)])
-def test_certified_signs_agree_with_exact_values(pkg, ob, cfg, half, ppc):
-    """The certificate as the march uses it (index coordinates linear in t, fp32 mean, sigma/norm
-    folded): every certified sign along real camera and shadow rays equals the exact value's sign."""
-    params = pkg.params_for_config(cfg)
-    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
-    med.build_guide(half, ppc)
+def _far_bundle(rng, template, dist, n=256):
+    """n rays whose origins lie `dist` world units from the medium and whose segments [dist - 1.5, dist + 1.5] cross it:
+    large ray parameters and origin coordinates in fp32 (the guide's index coordinates are anchored at near_t for these)"""
+    far = template[:n].copy()
+    d = np.column_stack([rng.uniform(-0.02, 0.02, n), rng.uniform(-0.02, 0.02, n), np.ones(n)])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    far["pos"] = (dist * d).astype(np.float32)
+    aim = -d + rng.uniform(-0.1 / dist, 0.1 / dist, (n, 3))
+    far["dir"] = (aim / np.linalg.norm(aim, axis=1, keepdims=True)).astype(np.float32)
+    far["near_t"] = dist - 1.5
+    far["far_t"] = dist + 1.5
+    return far
+
+
+def _raycheck_bundles(pkg, ob, med, orc, cfg, label):
     scene = ob.default_scene_s(320, 180, 1)
     rays, us = scene_rays(ob, orc, scene, step=3)
     sh = shadow_rays_from(ob, scene, rays, us, orc.sample_distance(rays))
-    # a bundle far from the origin whose rays enter the tabulated volume late (large |a|, |t*b|)
     rng = np.random.default_rng(11)
-    far = rays[:256].copy()
-    d = np.column_stack([rng.uniform(-0.02, 0.02, 256), rng.uniform(-0.02, 0.02, 256), np.ones(256)])
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    far["pos"] = (44.0 * d).astype(np.float32)
-    aim = -d + rng.uniform(-0.004, 0.004, (256, 3))
-    far["dir"] = (aim / np.linalg.norm(aim, axis=1, keepdims=True)).astype(np.float32)
-    far["near_t"] = 42.5
-    far["far_t"] = 45.5
+    # bundles whose near_t is 0, i.e. whose anchor is the distant origin itself: 15 world units (141 cells) away the
+    # unanchored magnitudes are still inside the error budget and steps are certified; 500 units away nothing is certified
+    near15 = _far_bundle(rng, rays, 15.0)
+    near15["near_t"] = 0.0
+    unanchored = _far_bundle(rng, rays, 500.0, n=64)
+    unanchored["near_t"] = 0.0
     total = 0
-    for batch in (rays, sh, far):
+    for name, batch, steps in (("camera", rays, 400), ("shadow", sh, 400), ("far 44", _far_bundle(rng, rays, 44.0), 400),
+                               ("far 500", _far_bundle(rng, rays, 500.0), 400), ("far 2000", _far_bundle(rng, rays, 2000.0), 400),
+                               ("origin 15, near_t 0", near15, 1700), ("origin 500, near_t 0", unanchored, 50300)):
         d = to_dev(batch)
-        certified, bad = med.guide_raycheck(d.data_ptr(), len(batch), 400)
-        print("%s %d:%d: %d rays, %d certified steps, %d violations" % (cfg, half, ppc, len(batch), certified, bad))
-        assert bad == 0
+        certified, bad = med.guide_raycheck(d.data_ptr(), len(batch), steps)
+        print("%s %s %s: %d rays, %d certified steps, %d violations" % (cfg, label, name, len(batch), certified, bad))
+        assert bad == 0, name
+        if name.startswith("far") or name.startswith("origin 15"):
+            assert certified > 50 * len(batch), name          # the far bundles ARE certified (their steps cross the field)
+        if name.startswith("origin 500"):
+            assert certified == 0, name
         total += certified
     assert total > 50 * len(rays)
+
+
+@pytest.mark.parametrize("cfg,half,ppc", [("C1", 16, 32), ("C0", 16, 16), ("C1", 6, 8)])
+def test_certified_signs_agree_with_exact_values(pkg, ob, cfg, half, ppc):
+    """The certificate as the march uses it (index coordinates linear in t and anchored at near_t, fp32 mean, sigma/norm
+    folded): every certified sign along real camera and shadow rays, and along bundles that start 44 / 500 / 2000 world
+    units away, equals the exact value's sign."""
+    params = pkg.params_for_config(cfg)
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    med.build_guide(half, ppc)
+    _raycheck_bundles(pkg, ob, med, orc, cfg, "%d:%d" % (half, ppc))
+
+
+def test_headline_guide_configuration_16_64(pkg, ob):
+    """The guide resolution bench.py runs the headline on (16:64: side 2048, 34 GB, the 24-bit row index and the 64-bit element
+    index at their largest): bound self-check over the whole tabulated volume, certificate ray-check on every bundle, and the
+    guided march against the oracle, field by field."""
+    params = pkg.params_for_config("C1")
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    med.build_guide(16, 64)
+    rng = np.random.default_rng(17)
+    pts = _cluster_points(rng, 16384, 16)
+    d = to_dev(pts)
+    checked, bad, ratio, bound = med.guide_selfcheck(d.data_ptr(), len(pts))
+    print("guide C1 16:64: checked %d, violations %d, max |err|/bound %.3f, mean bound %.3f" % (checked, bad, ratio, bound))
+    assert checked > 0.95 * len(pts) and bad == 0 and ratio < 1.0
+    _raycheck_bundles(pkg, ob, med, orc, "C1", "16:64")
+    scene = ob.default_scene_s(480, 270, 2)
+    rays, us = scene_rays(ob, orc, scene, step=6)
+    want = orc.sample_distance(rays)
+    got = med.sample_distance(rays)
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+    sh = shadow_rays_from(ob, scene, rays, us, want)
+    assert np.array_equal(med.transmittance(sh), orc.transmittance(sh))
+    # far bundles through the march itself (anchored index coordinates): bit-identical to the oracle
+    far = np.concatenate([_far_bundle(rng, rays, 500.0), _far_bundle(rng, rays, 2000.0)])
+    got, want = med.sample_distance(far), orc.sample_distance(far)
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+    assert np.array_equal(med.transmittance(far), orc.transmittance(far))
 
 
 def test_guided_march_matches_oracle_and_saves_evaluations(pkg, ob):

@@ -13,13 +13,21 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def _kernels(lib):
+    """kernel name -> resources, over every code object of the library (one offload bundle per translation unit)"""
     tmp = tempfile.mkdtemp()
+    notes = ""
     try:
-        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        fat = os.path.join(tmp, "fat.bin")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
-        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True, stderr=subprocess.DEVNULL)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        for i, a in enumerate(starts):
+            part, co = os.path.join(tmp, "b%d.bin" % i), os.path.join(tmp, "b%d.co" % i)
+            open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part, "--output=" + co])
+            notes += subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True, stderr=subprocess.DEVNULL)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {}
@@ -46,8 +54,8 @@ def test_hot_kernels_keep_their_budget(pkg):
         assert v["vgpr_count"] <= 96 and v["private_segment_fixed_size"] <= 360, v
     for v in one("k_fast_sample_distance"):
         assert v["private_segment_fixed_size"] == 0, v
-    for sub, scratch in (("spec_3d7PersistE", 0), ("16spec_3d_multires7PersistE", 64), ("spec_1d7PersistE", 160)):
-        for v in one("k_persist_marchIN4gpis" + ("7" if not sub[0].isdigit() else "") + sub):
+    for sub, scratch in (("7spec_3d7PersistE", 0), ("16spec_3d_multires7PersistE", 64), ("7spec_1d7PersistE", 160)):
+        for v in one("k_persist_marchINS_" + sub):
             assert v["vgpr_count"] <= 168 and v["private_segment_fixed_size"] <= scratch, (sub, v)   # 3 waves/SIMD
             assert v["group_segment_fixed_size"] <= 16 * 1024
     for v in one("k_fs_marchILb"):                        # four workgroups per CU (one per SIMD), no scratch

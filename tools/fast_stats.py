@@ -12,8 +12,8 @@ prebuilt = os.path.join(ROOT, "build", "stats", "libgpis_hip_stats.so")
 if os.path.exists(prebuilt):
     so = prebuilt
 else:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                           "-DGPIS_FAST_STATS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", so, os.path.join(csrc, "gpis_hip.hip"), os.path.join(csrc, "gpis_sort.hip")])
+    import __graft_entry__ as g
+    g.build_hip(extra_flags=("-DGPIS_FAST_STATS",), out=so)        # every translation unit with the counters compiled in
 import torch
 lib = pkg.GpisLib(so)
 w, h, spp = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (480, 270, 64)))

@@ -81,9 +81,15 @@ def main():
             pass
     isa = args.isa
     if isa is None:
+        # the march kernels live in their own translation units (csrc/gpis_launch.hpp): one listing of all of them
         isa = os.path.join(tempfile.gettempdir(), "gpis_hip_model.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-I", os.path.join(ROOT, "include"),
-                               "-I", CSRC, "-S", "--cuda-device-only", "-o", isa, os.path.join(CSRC, "gpis_hip.hip")], stderr=subprocess.DEVNULL)
+        with open(isa, "w") as f_out:
+            for unit in ("tu_guided_sd.hip", "tu_guided_tr.hip", "tu_fast.hip", "tu_persist_a.hip", "tu_persist_b.hip", "tu_generic_nee.hip"):
+                part = isa + "." + unit
+                subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                                       "-I", CSRC, "-S", "--cuda-device-only", "-o", part, os.path.join(CSRC, unit)], stderr=subprocess.DEVNULL)
+                f_out.write(open(part).read())
+                os.remove(part)
     costs, _ = im.cost_table(args.micro)
     compulsory = json.load(open(args.compulsory)) if args.compulsory else {}
     sys.path.insert(0, ROOT)
