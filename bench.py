@@ -10,8 +10,8 @@ frame without the guide field (every march step evaluated exactly).
 
 `python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed / RCCL): rank 0
 broadcasts the parameter block, the image's 16-pixel tile rows are dealt round-robin to the ranks (the tile
-split of the reference's integrator: the SAME image at every N, strong scaling), and the disjoint partial
-images are assembled with ONE reduce(sum) to rank 0 inside the timed region.
+split of the reference's integrator: the SAME image at every N, strong scaling), and the disjoint tile rows
+are assembled with ONE gather to rank 0 inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -190,13 +190,28 @@ def dry_run(args, world, rank):
             idx = torch.arange(y * W, (y + 1) * W)
             acc[idx] += (1 + idx % 7).to(torch.float32) * k
 
-    pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard)
+    st = pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard)
+    # what this rank's driver call would do on the GPU: the scene-S driver marches its share in chunks of at most 2^27 samples
+    # (375 B of workspace per sample, csrc/gpis_hip.hip: gpis_render_scene_s), one launch per stage and chunk
+    my_rows = len(pkg.dist.shard_rows(scene, rank, world, 16)) if args.shard == "rows" else H
+    my_samples = my_rows * W * spp
+    chunk_samples = min(((1 << 27) // spp) * spp, my_samples) if my_samples else 0
+    plan = torch.tensor([my_rows, my_samples, -(-my_samples // chunk_samples) if chunk_samples else 0, chunk_samples * 375, st["wire_bytes"]], dtype=torch.float64)
+    plans = [torch.zeros_like(plan) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(plans, plan)
+    else:
+        plans = [plan]
     if rank == 0:
         idx = torch.arange(H * W)
         want = (1 + idx % 7).to(torch.float32) * pkg.dist.total_spp(scene, world, args.shard)
         print(json.dumps({"metric": "dry-run (no GPU work)", "dry_run": True, "value": None, "n_gpus": world,
                           "ranks_seen": dist.get_world_size() if world > 1 else 1, "shard": args.shard,
-                          "coverage_ok": bool(torch.equal(rad, want)), "impulse_density": float(params["impulse_density"])}))
+                          "coverage_ok": bool(torch.equal(rad, want)), "impulse_density": float(params["impulse_density"]),
+                          "plan": {"rows_per_rank": [int(p[0]) for p in plans], "samples_per_rank": [int(p[1]) for p in plans],
+                                   "chunks_per_rank": [int(p[2]) for p in plans], "workspace_bytes_per_rank": [int(p[3]) for p in plans],
+                                   "wire_bytes_per_rank": [int(p[4]) for p in plans],
+                                   "samples_total": int(sum(p[1] for p in plans))}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -219,6 +234,10 @@ def main():
     ap.add_argument("--guide", default="16:64", help="certified guide field 'half_extent_cells:points_per_cell' for "
                     "single-realization media, or 'off' (built once before the timed region: 34 GB / 2 s at 16:64, "
                     "4.3 GB / 0.3 s at 16:32; falls back to 16:32 if the allocation fails)")
+    ap.add_argument("--estimator", choices=["auto", "lambert", "nee"], default="auto",
+                    help="auto: C2 (1D sampling, MIS, conductor) renders through the conductor NEE estimator (gpis_render_scene_s_nee, "
+                         "TraceBase.cpp:346-420 / ConductorBsdf.cpp:68-137) as BASELINE.json states it, everything else through scene S's "
+                         "Lambert + one shadow ray estimator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unguided", action="store_true", help="skip the extra unguided frame (value_unguided)")
     args = ap.parse_args()
@@ -278,13 +297,22 @@ def main():
         guide_info = {"half_extent_cells": half, "points_per_cell": ppc, "bytes": (2 * half * ppc) ** 3 * 4,
                       "build_s": time.perf_counter() - t_g}
 
+    use_nee = args.estimator == "nee" or (args.estimator == "auto" and args.config == "C2")
+    surf = np.array(pkg.default_surface_s(), dtype=pkg.SURFACE_S)
+
     def render_into(part, acc):
-        med.call("gpis_render_scene_s", part.ctypes.data_as(ctypes.c_void_p), acc.data_ptr(), None, stream)
+        if use_nee:
+            med.call("gpis_render_scene_s_nee", part.ctypes.data_as(ctypes.c_void_p), surf.ctypes.data_as(ctypes.c_void_p), acc.data_ptr(), stream)
+        else:
+            med.call("gpis_render_scene_s", part.ctypes.data_as(ctypes.c_void_p), acc.data_ptr(), None, stream)
+
+    rank_stats = []
 
     def step():
         rad.zero_()
-        # "rows": 16-pixel tile rows dealt round-robin, one batch per rank, one reduce(sum) of the disjoint partial images
-        pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard)
+        # "rows": 16-pixel tile rows dealt round-robin, one batch per rank, ONE gather of the disjoint tile rows to rank 0
+        rank_stats.append(pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard,
+                                                  sync=torch.cuda.synchronize))
 
     step()
     fence()
@@ -296,6 +324,7 @@ def main():
     fence()
     med.reset_counters()
     med.set_profiling(True)
+    del rank_stats[:]
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -308,8 +337,20 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt_max, dt_cold_max = float(tt[0].item()), float(tt[1].item())
+    # per-rank diagnostics (N > 1): every rank's own render and collective time per frame and its guide-field build, so that an
+    # imbalance of the interleaved tile rows or one slow guide build is visible behind the max-over-ranks metric
+    mine = torch.tensor([sum(r["render_s"] for r in rank_stats) / max(len(rank_stats), 1) * 1e3,
+                         sum(r["collective_s"] for r in rank_stats) / max(len(rank_stats), 1) * 1e3,
+                         guide_info["build_s"] if guide_info else 0.0, float(rank_stats[-1]["wire_bytes"]) if rank_stats else 0.0], dtype=torch.float64, device="cuda")
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    per_rank = [[float(v) for v in t.cpu()] for t in per_rank]
 
     prof = [med.kernel_profile(k) for k in (0, 1)]     # (ms, launches, n_eval, n_seg)
+    prof_nee = med.kernel_profile(2) if use_nee else None
     n_guide = med.guide_steps() if guide_info else 0
 
     # ---- the same frame without the guide field: every march step evaluated exactly (N = 1 only; one frame) — and the
@@ -348,6 +389,11 @@ def main():
                     "frac": None, "traffic": None, "note": "profiles/r02_issue_model.json not found"}
         if True:
             roof["kernel_ms"] = {names[0]: prof[0][0] / max(prof[0][1], 1), names[1]: prof[1][0] / max(prof[1][1], 1)}     # per launch
+            if prof_nee:
+                # per frame: the march kernels (one sampleDistance, two masked transmittance launches) and the two k_nee launches
+                per_frame = {"sample_distance": prof[0][0] / args.steps, "transmittance": prof[1][0] / args.steps, "k_nee": prof_nee[0] / args.steps}
+                roof["kernel_ms_per_frame"] = per_frame
+                roof["k_nee_share_of_kernel_time"] = per_frame["k_nee"] / max(sum(per_frame.values()), 1e-9)
             roof["launches"] = launches
             roof["evals_per_s"] = n_eval_all / dt_max
             roof["certified_steps_per_s"] = n_guide / dt_max
@@ -366,8 +412,12 @@ def main():
             "higher_is_better": True, "scaling": "weak" if args.shard == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: scene S %dx%d, %d spp, SparseConvolutionNoiseMedium (3D isotropic, "
                                    "impulse_density=%d, ctx=renewal, single_realization)" % (args.config, W, H, spp, int(params["impulse_density"]))
-                       if args.config == "C1" else "%s: scene S %dx%d, %d spp" % (args.config, W, H, spp),
-                       "sharding": ("%s: 16-pixel tile rows dealt round-robin, one batch per rank, reduce(sum) of disjoint partial images to rank 0" % args.shard
+                       if args.config == "C1" else
+                       ("C2: scene S %dx%d, %d spp, 1D sampling, 1D_sampling_scheme=mis (NEE on), Renewal+ memory, conductor BSDF "
+                        "(gpis_render_scene_s_nee: volumeLightSample + volumePhaseSample with neePDF / neeGrad, one cap light)" % (W, H, spp)
+                        if use_nee else "%s: scene S %dx%d, %d spp" % (args.config, W, H, spp)),
+                       "estimator": "conductor NEE / MIS (TraceBase.cpp:346-420, ConductorBsdf.cpp:68-137)" if use_nee else "Lambert + one shadow ray",
+                       "sharding": ("%s: 16-pixel tile rows dealt round-robin, one batch per rank, one gather of the disjoint tile rows to rank 0" % args.shard
                                     if args.shard == "rows" else "spp slices per rank + reduce(sum) to rank 0") if world > 1 else "single GPU",
                        "kernel_path": ("guided (certified guide field + wave-cooperative exact evaluations)" if guide_info else
                                        "fast (wave-cooperative)") if fast else ("per-path: persistent refilling march" if persistent else "per-path: one ray per lane"),
@@ -375,6 +425,11 @@ def main():
                        "value_cold_doc": "one frame with gpis_create (cell table), the guide-field build and the workspace allocation inside the timer (%.2f s)" % dt_cold_max,
                        "value_unguided_doc": "one frame after gpis_drop_guide: every march step is an exact wave-cooperative evaluation" if dt_unguided else None},
             "roofline": roof,
+            "per_rank": None if world == 1 else {
+                "render_ms": {"min": min(p[0] for p in per_rank), "max": max(p[0] for p in per_rank), "mean": sum(p[0] for p in per_rank) / world, "all": [p[0] for p in per_rank]},
+                "collective_ms": {"max": max(p[1] for p in per_rank), "all": [p[1] for p in per_rank]},
+                "guide_build_s": [p[2] for p in per_rank], "wire_bytes_per_frame": [int(p[3]) for p in per_rank],
+                "doc": "each rank's own clock around its share of a frame (device synchronised) and around the gather / reduce"},
         }
         if not args.no_cpu_baseline and world == 1:
             cores = usable_cores()

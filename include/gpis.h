@@ -73,17 +73,22 @@ typedef enum gpis_mean_type {
     GPIS_MEAN_LINEAR = 2         /* max((p-ref).dir*scale, min)  GPF.hpp:947-1005 */
 } gpis_mean_type;
 
-/* ProceduralNoiseVec ramps used for the non-stationary length scale, GPF.cpp:87-95. */
+/* NoiseType of ProceduralNoise / ProceduralNoiseVec (GPF.hpp:613-650, 702-739): the four ramps (GPF.cpp:57-69, 91-103) and
+ * the two fbm noises over 3D simplex noise (GPF.cpp:70-83, 104-117; math/SdfFunctions.cpp:199-296). */
 typedef enum gpis_ramp_type {
     GPIS_RAMP_BOTTOM_TOP = 0,    /* along y */
     GPIS_RAMP_LEFT_RIGHT = 1,    /* along x */
     GPIS_RAMP_FRONT_BACK = 2,    /* along z */
-    GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT = 3   /* product of a y ramp and an x ramp ("min2".."end2"), GPF.cpp:96-103 */
+    GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT = 3,  /* product of a y ramp and an x ramp ("min2".."end2"), GPF.cpp:96-103 */
+    GPIS_NOISE_SANDSTONE = 4,    /* "sandstone": three nested fbm, scalar fields lerp(min, max, .), vector fields clamp(0.2 col) */
+    GPIS_NOISE_RUST = 5          /* "rust": smoothStep(0.4, 0.6, fbm -/+ 0.1 fbm(25 p)), scalar lerp(min, max, .), vector lerp((0.278, 0.212, 0.141), 1, .) */
 } gpis_ramp_type;
 
-/* A procedural field of type "noise" (ProceduralNoise / ProceduralNoiseVec, GPF.hpp:596-776, GPF.cpp:43-138) with one of the
- * ramp noises; "sandstone" / "rust" are outside the built scope.  Used for the variance field ("var"), and for the mean's
- * "color" / "emission" (a vector field whose three components are equal for the ramp noises). */
+/* A procedural field of type "noise" (ProceduralNoise / ProceduralNoiseVec, GPF.hpp:596-776, GPF.cpp:43-138).  Used for the
+ * scalar fields "var" (variance) and "aniso" (ProceduralNoise: 2 fbm octaves) and for the vector fields "ls" (the kernel scale
+ * is the largest component, GPF.cpp:1729-1735) and the mean's "color" / "emission" (ProceduralNoiseVec: 10 octaves; the three
+ * components are equal for the ramp noises and differ for sandstone / rust).  On the device `sin` / `sqrt` of the fbm hash are
+ * ocml's, not glibc's: values agree with the CPU to the stated tolerance, not bit for bit. */
 typedef struct gpis_ramp {
     int32_t enabled;
     int32_t type;                    /* gpis_ramp_type */
@@ -371,6 +376,19 @@ int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, fl
  * workspace per handle: launches of the SAME handle must be ordered (one stream, or an event between them). */
 int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream);
 int gpis_fs_transmittance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible, void *stream);
+/* The same two entries for host pointers (synchronous; what the Medium binding of the function-space medium calls with a batch
+ * of one, integration/HipFunctionSpaceMedium.cpp): rays, states and results are staged through the handle's device buffers. */
+int gpis_fs_sample_distance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out);
+int gpis_fs_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible);
+
+/* Test surface of the function-space path's dense linear algebra: `count` n x n column-major matrices of doubles (device
+ * pointers, 1 <= n <= GPIS_FS_MAX_CTX), one wave each.  op GPIS_FS_OP_EIGH: Eigen::SelfAdjointEigenSolver<MatrixXd> (lower
+ * triangle read; eigenvectors -> out, eigenvalues ascending -> evals, which may be NULL); GPIS_FS_OP_NORM_TRANSFORM:
+ * MultivariateNormalDistribution's normTransform (Eigen::LLT, else eigenvectors x sqrt(max(eigenvalues, 0)), Gaussian.cpp:
+ * 121-167); GPIS_FS_OP_PINV: pseudo_inverse (GaussianProcess.cpp:645-662).  Results are bit-identical to the reference's
+ * vendored Eigen under the reference's build flags (tests/golden/ref_fs_primitives.npz). */
+typedef enum gpis_fs_linalg_op { GPIS_FS_OP_EIGH = 0, GPIS_FS_OP_NORM_TRANSFORM = 1, GPIS_FS_OP_PINV = 2 } gpis_fs_linalg_op;
+int gpis_fs_linalg_batch(gpis_medium *m, int op, int n, size_t count, const double *in, double *out, double *evals, void *stream);
 
 /* Bit-exact primitives (MathUtil.hpp:179-224, UniformSampler.hpp:41-75, BitManip.hpp:47-50):
  * out[i] = xxhash32 of `arity` (1..4) words at words[i*arity..]; and the PCG32 stream
@@ -408,7 +426,8 @@ int gpis_reset_counters(gpis_medium *m);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around every march-kernel
  * launch (off by default; events cost a few microseconds per launch).  `which`: 0 = the
- * sampleDistance kernel, 1 = the transmittance kernel.  Returns the summed kernel time, the
+ * sampleDistance kernel, 1 = the transmittance kernel, 2 = the neePDF / neeGrad launches of
+ * gpis_render_scene_s_nee (time and launches only).  Returns the summed kernel time, the
  * number of launches, and that kernel's share of the evaluation / segment counters since the
  * last gpis_reset_counters.  Synchronises the device. */
 int gpis_set_profiling(gpis_medium *m, int enable);

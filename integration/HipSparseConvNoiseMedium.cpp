@@ -385,7 +385,12 @@ Vec3f HipSparseConvNoiseMedium::transmittance(PathSampleGenerator &sampler, cons
     fillRay(ray, *state, sampler.next1D(), r);
     if (gpis_transmittance_host(_handle, 1, &r, &visible) != GPIS_OK)
         return Vec3f(0.0f);
-    state->firstScatter = false;
+    // GaussianProcessMedium.cpp:371-381: firstScatter is cleared (and lastAniso set to the hit's gradient) on a hit only.  The device
+    // skips that gradient — transmittance() cannot return it and the reference's callers run shadow segments on a state COPY
+    // (TraceBase.cpp:79-85, 291-293) — so lastAniso is left as it was: an integrator that reads it after a blocked shadow segment
+    // needs sampleDistance instead.
+    if (!visible)
+        state->firstScatter = false;
     return visible ? Vec3f(1.0f) : Vec3f(0.0f);
 }
 

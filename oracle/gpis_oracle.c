@@ -390,22 +390,126 @@ static double ramp_eval(int type, double mn, double mx, double start, double end
     double coord = type == GPIS_RAMP_BOTTOM_TOP ? p.y : (type == GPIS_RAMP_LEFT_RIGHT ? p.x : p.z);
     return ramp_unit(coord, start, end, mn, mx) - c;
 }
+/* ---- "sandstone" / "rust": fbm over 3D simplex noise, math/SdfFunctions.cpp:199-296.  Pinned bit for bit against the
+ * reference's own SdfFunctions.cpp compiled in place (oracle/_ref: ref_random3 / ref_simplex3d / ref_fbm,
+ * tests/test_oracle_vs_ref.py).  `sin` of the float dot product resolves to the double function there. */
+static inline float sdf_dot3(v3f a, v3f b) { float r = a.x * b.x; r += a.y * b.y; r += a.z * b.z; return r; }
+static v3f sdf_random3(v3f c)                                  /* SdfFunctions.cpp:199-208 */
+{
+    const v3f k = {17.0f, 59.4f, 15.0f};
+    float j = (float)(4096.0 * sin((double)sdf_dot3(c, k)));
+    v3f r; double v;
+    v = 512.0 * (double)j; r.z = (float)(v - floor(v));
+    j = (float)((double)j * .125);
+    v = 512.0 * (double)j; r.x = (float)(v - floor(v));
+    j = (float)((double)j * .125);
+    v = 512.0 * (double)j; r.y = (float)(v - floor(v));
+    r.x = r.x - 0.5f; r.y = r.y - 0.5f; r.z = r.z - 0.5f;
+    return r;
+}
+static float sdf_simplex3d(v3f p)                              /* SdfFunctions.cpp:228-273 */
+{
+    const float F3 = 0.3333333f, G3 = 0.1666667f;              /* :211-212 */
+    const v3f f3 = {F3, F3, F3}, g3 = {G3, G3, G3};
+    const float pf = sdf_dot3(p, f3);
+    v3f s = {floorf(p.x + pf), floorf(p.y + pf), floorf(p.z + pf)};
+    const float sg = sdf_dot3(s, g3);
+    const v3f x = {(p.x - s.x) + sg, (p.y - s.y) + sg, (p.z - s.z) + sg};
+    const v3f e = {(x.x - x.y) < 0.0f ? 0.f : 1.f, (x.y - x.z) < 0.0f ? 0.f : 1.f, (x.z - x.x) < 0.0f ? 0.f : 1.f};   /* step(0, x - x.yzx) */
+    const v3f ez = {e.z, e.x, e.y};
+    const v3f i1 = {e.x * (1.0f - ez.x), e.y * (1.0f - ez.y), e.z * (1.0f - ez.z)};
+    const v3f i2 = {1.0f - ez.x * (1.0f - e.x), 1.0f - ez.y * (1.0f - e.y), 1.0f - ez.z * (1.0f - e.z)};
+    const float g2 = 2.0f * G3, g3s = 3.0f * G3;
+    const v3f x1 = {(x.x - i1.x) + G3, (x.y - i1.y) + G3, (x.z - i1.z) + G3};
+    const v3f x2 = {(x.x - i2.x) + g2, (x.y - i2.y) + g2, (x.z - i2.z) + g2};
+    const v3f x3 = {(x.x - 1.0f) + g3s, (x.y - 1.0f) + g3s, (x.z - 1.0f) + g3s};
+    float w[4] = {sdf_dot3(x, x), sdf_dot3(x1, x1), sdf_dot3(x2, x2), sdf_dot3(x3, x3)}, d[4];
+    for (int i = 0; i < 4; ++i) { const float t = 0.6f - w[i]; w[i] = t < 0.0f ? 0.0f : t; }     /* max(0.6 - w, 0) */
+    const v3f s1 = {s.x + i1.x, s.y + i1.y, s.z + i1.z}, s2 = {s.x + i2.x, s.y + i2.y, s.z + i2.z}, s3 = {s.x + 1.0f, s.y + 1.0f, s.z + 1.0f};
+    d[0] = sdf_dot3(sdf_random3(s), x);
+    d[1] = sdf_dot3(sdf_random3(s1), x1);
+    d[2] = sdf_dot3(sdf_random3(s2), x2);
+    d[3] = sdf_dot3(sdf_random3(s3), x3);
+    for (int i = 0; i < 4; ++i) { w[i] *= w[i]; w[i] *= w[i]; d[i] *= w[i]; }
+    float r = d[0] * 52.0f; r += d[1] * 52.0f; r += d[2] * 52.0f; r += d[3] * 52.0f;
+    return r;
+}
+static double sdf_fbm(v3d uv, int octaves)                     /* SdfFunctions.cpp:276-296 */
+{
+    const float gain = 0.65f, lacunarity = 2.1042f;
+    float total, frequency = 0.5f, amplitude = gain;
+    const v3f u = {(float)(uv.x * 5.0), (float)(uv.y * 5.0), (float)(uv.z * 5.0)};
+    total = sdf_simplex3d(u);
+    for (int i = 0; i < octaves; i++) {
+        const v3f q = {u.x * frequency, u.y * frequency, u.z * frequency};
+        total += sdf_simplex3d(q) * amplitude;
+        frequency *= lacunarity;
+        amplitude *= gain;
+    }
+    total = (float)(((double)total + 2.0) / 4.0);
+    return (double)total;
+}
+static inline v3d v3d_adds(v3d a, double s) { v3d r = {a.x + s, a.y + s, a.z + s}; return r; }
+static inline v3d v3d_muls(v3d a, double s) { v3d r = {a.x * s, a.y * s, a.z * s}; return r; }
+static inline double clamp01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }     /* MathUtil clamp: min(max(v, lo), hi) */
+static inline double smooth_step(double e0, double e1, double x) { x = clamp01((x - e0) / (e1 - e0)); return x * x * (3.0 - 2.0 * x); }   /* MathUtil.hpp:107-112 */
+/* the fbm cascades shared by ProceduralNoise (octaves 2) and ProceduralNoiseVec (octaves 10), GPF.cpp:70-83, 104-117 */
+static double noise_sandstone_f(v3d p, int oct)
+{
+    const v3d ps = v3d_muls(p, 0.3);
+    return sdf_fbm(v3d_adds(ps, sdf_fbm(v3d_adds(ps, sdf_fbm(ps, oct)), oct)), oct);
+}
+/* ProceduralNoise::operator() (the SCALAR fields "var" and "aniso"), GPF.cpp:53-85 */
 static double ramp_of(const gpis_ramp *r, v3d p)
 {
+    if (r->type == GPIS_NOISE_SANDSTONE) {
+        const double f = noise_sandstone_f(p, 2);
+        const double colx = sqrt((f * 1.9) * 1.2) - 0.35;
+        const double t = clamp01(colx);
+        return r->min * (1.0 - t) + r->max * t;                                   /* lerp(_min, _max, .) */
+    }
+    if (r->type == GPIS_NOISE_RUST) {
+        const v3d ps = v3d_muls(p, 2.0);
+        const double f = smooth_step(0.4, 0.6, sdf_fbm(v3d_adds(ps, sdf_fbm(v3d_muls(ps, .1), 2) * 0.4), 2) - sdf_fbm(v3d_muls(ps, 25.), 2) * 0.1);
+        const double t = clamp01(f);
+        return r->min * (1.0 - t) + r->max * t;
+    }
     return ramp_eval(r->type, r->min, r->max, r->start, r->end, r->min2, r->max2, r->start2, r->end2, p);
 }
-static double ls_ramp(const oracle_medium *m, v3d p)
+/* ProceduralNoiseVec::operator() (the VECTOR fields "ls", mean "color" / "emission"), GPF.cpp:87-120: the ramp noises have
+ * three equal components, sandstone / rust do not (and use 10 octaves, and rust ADDS its fine-scale term) */
+static void noise_vec(int type, double mn, double mx, double start, double end, double mn2, double mx2, double start2, double end2, v3d p, double out[3])
 {
-    const gpis_params *P = &m->P;
-    return ramp_eval(P->ls_ramp_type, P->ls_min, P->ls_max, P->ls_start, P->ls_end, P->ls_min2, P->ls_max2, P->ls_start2, P->ls_end2, p);
+    if (type == GPIS_NOISE_SANDSTONE) {
+        const double f = noise_sandstone_f(p, 10);
+        const double col[3] = {sqrt((f * 1.9) * 1.2) - 0.35, sqrt((f * 0.7) * 1.2) - 0.35, sqrt((f * 0.25) * 1.2) - 0.35};
+        for (int c = 0; c < 3; ++c) out[c] = clamp01(col[c] * 0.2);
+        return;
+    }
+    if (type == GPIS_NOISE_RUST) {
+        const v3d ps = v3d_muls(p, 2.0);
+        const double f = smooth_step(0.4, 0.6, sdf_fbm(v3d_adds(ps, sdf_fbm(v3d_muls(ps, .1), 10) * 0.4), 10) + sdf_fbm(v3d_muls(ps, 25.), 10) * 0.1);
+        const double a[3] = {0.278, 0.212, 0.141};
+        for (int c = 0; c < 3; ++c) out[c] = a[c] * (1.0 - f) + 1. * f;            /* Vec lerp: a*(1 - ratio) + b*ratio, MathUtil.hpp:101-105 */
+        return;
+    }
+    out[0] = out[1] = out[2] = ramp_eval(type, mn, mx, start, end, mn2, mx2, start2, end2, p);
+}
+static void ramp_vec_of(const gpis_ramp *r, v3d p, double out[3])
+{
+    noise_vec(r->type, r->min, r->max, r->start, r->end, r->min2, r->max2, r->start2, r->end2, p, out);
 }
 /* sparseConvNoiseLateralScale: GPF.cpp:607-609 / 1219-1221 → getKernelScale GPF.cpp:1729-1735 */
 static float cov_lateral_scale(const oracle_medium *m, v3f p)
 {
     if (!m->P.nonstationary)
         return 1.0f;
-    float ls = (float)ls_ramp(m, v3d_of(p));
-    return ls;  /* max(max(ls,ls),ls) */
+    const gpis_params *P = &m->P;
+    double ls[3];
+    noise_vec(P->ls_ramp_type, P->ls_min, P->ls_max, P->ls_start, P->ls_end, P->ls_min2, P->ls_max2, P->ls_start2, P->ls_end2, v3d_of(p), ls);
+    const float lx = (float)ls[0], ly = (float)ls[1], lz = (float)ls[2];
+    const float mxy = lx < ly ? ly : lx;                                          /* max(a, b): a < b ? b : a */
+    return mxy < lz ? lz : mxy;
 }
 /* sparseConvNoiseMaxLateralScale, GPF.cpp:1737-1741 */
 static float cov_max_lateral_scale(const oracle_medium *m) { return m->P.nonstationary ? m->ls_maxval : 1.f; }
@@ -427,8 +531,60 @@ static float cov_amplitude(const oracle_medium *m, v3f p)
     double var = m->P.var.enabled ? ramp_of(&m->P.var, v3d_of(p)) : 1.0;
     return (float)(var * m->P.sigma);
 }
-/* ---- Matérn (v = 0.5, 2.5) and Gabor kernels: GPF.cpp:866-1214 ---------------------------------------------
+/* ---- Matérn (v = 0.5, 1.5, 2.5) and Gabor kernels: GPF.cpp:866-1214 ---------------------------------------------
  * The reference evaluates these in double (exp / pow / cos / sin of libm) and narrows to float. */
+/* Modified Bessel functions of the second kind K0(x), K1(x), x > 0, for the Matern v = 3/2 splatting kernel (GPF.cpp:1053-1056,
+ * 1071-1074 call boost::math::cyl_bessel_k, which is neither vendored nor installed: PARITY UNPINNED VS BOOST; these are checked
+ * against the Wronskian I0 K1 + I1 K0 = 1/x and against scipy to 1e-14 in tests/).  x <= 2: the ascending series
+ *   K0 = -(ln(x/2) + g) I0 + sum_k (x^2/4)^k / (k!)^2 H_k,   K1 = 1/x + ln(x/2) I1 - (x/4) sum_k (psi(k+1) + psi(k+2)) (x^2/4)^k / (k! (k+1)!);
+ * x > 2: Steed's algorithm on the continued fraction CF2 (Temme 1975), which converges in < 40 terms there. */
+static void bessel_k01(double x, double *k0, double *k1)
+{
+    const double EULER = 0.57721566490153286061;
+    if (x <= 2.0) {
+        const double q = 0.25 * x * x, lg = log(0.5 * x);
+        double term0 = 1.0, i0 = 1.0, s0 = 0.0, hk = 0.0;           /* term0 = q^k / (k!)^2 */
+        double term1 = 1.0, i1s = 1.0, s1 = 1.0 - 2.0 * EULER;       /* term1 = q^k / (k! (k+1)!), s1 = sum (psi(k+1) + psi(k+2)) term1 */
+        double hk1 = 1.0;                                            /* H_{k+1} */
+        for (int k = 1; k < 40; ++k) {
+            term0 *= q / ((double)k * (double)k);
+            hk += 1.0 / (double)k;
+            i0 += term0;
+            s0 += term0 * hk;
+            term1 *= q / ((double)k * (double)(k + 1));
+            hk1 += 1.0 / (double)(k + 1);
+            i1s += term1;
+            s1 += term1 * ((hk - EULER) + (hk1 - EULER));            /* psi(k+1) = H_k - g */
+            if (term0 < 1e-18 * i0) break;
+        }
+        *k0 = -(lg + EULER) * i0 + s0;
+        *k1 = 1.0 / x + lg * (0.5 * x * i1s) - 0.25 * x * s1;
+        return;
+    }
+    {
+        double b = 2.0 * (1.0 + x), d = 1.0 / b, h = d, delh = d, q1 = 0.0, q2 = 1.0;
+        const double a1 = 0.25;
+        double qq = a1, c = a1, a = -a1, s = 1.0 + qq * delh;
+        for (int i = 2; i <= 500; ++i) {
+            a -= 2.0 * (double)(i - 1);
+            c = -a * c / (double)i;
+            const double qnew = (q1 - b * q2) / a;
+            q1 = q2; q2 = qnew;
+            qq += c * qnew;
+            b += 2.0;
+            d = 1.0 / (b + a * d);
+            delh = (b * d - 1.0) * delh;
+            h += delh;
+            const double dels = qq * delh;
+            s += dels;
+            if (fabs(dels / s) < 1e-17) break;
+        }
+        h = a1 * h;
+        const double rk0 = sqrt(3.14159265358979323846 / (2.0 * x)) * exp(-x) / s;
+        *k0 = rk0;
+        *k1 = rk0 * (x + 0.5 - h) / x;
+    }
+}
 static float other_kernel_radius(const oracle_medium *m, int isIdentity, float localScale)
 {
     float scale_factor = m->kernel_scale;
@@ -455,6 +611,7 @@ static float other_variance3d(const oracle_medium *m, float impulseDensity, floa
     const float l = m->P.length_scale, a = m->gabor_a, f = m->gabor_f;
     if (m->P.kernel_type == GPIS_KERNEL_MATERN) {                        /* GPF.cpp:1029-1046 */
         if (m->P.matern_v == 0.5) integralKernelSquared = 2.0 * M_PI * l;
+        else if (m->P.matern_v == 1.5) integralKernelSquared = pow(M_PI * l, 3) / (24 * sqrt(3));
         else integralKernelSquared = M_PI * pow(l, 3) / (5 * sqrt(5));
     } else if (m->P.kernel_type == GPIS_KERNEL_GABOR_ANISO) {            /* GPF.cpp:1134-1138 */
         float q = f / a;
@@ -474,6 +631,11 @@ static v4f other_splat3d(const oracle_medium *m, v3f ab)
         if (m->P.matern_v == 0.5) {
             val = (float)(exp(-abLen / l) / abLen);
             gs = -(float)(exp(-abLen / l) * (1 / pow(abLen, 3) - 1 / (pow(abLen, 2) * l)));
+        } else if (m->P.matern_v == 1.5) {                                /* GPF.cpp:1053-1056, 1071-1074 */
+            double r_scl = sqrt(3.) * abLen / l, k0, k1;
+            bessel_k01(r_scl, &k0, &k1);
+            val = (float)k0;
+            gs = -(float)(k1 * sqrt(3.) / l / abLen);
         } else {
             val = (float)exp(-sqrt(5.) * abLen / l);
             gs = -(float)(exp(-sqrt(5.) * abLen / l) * sqrt(5.) / l / abLen);
@@ -1579,9 +1741,9 @@ static void sample_distance_one(const oracle_medium *m, oracle_counters *cnt, co
             }
             /* sample.weight = sample.continuedWeight = vec_conv<Vec3f>(_gp->color(ro + rd * t)), GPM.cpp:316; MeanFunction::color
              * is 1 without a "color" field (GPF.hpp:849-852) */
-            float col = m->P.mean_color.enabled ? (float)ramp_of(&m->P.mean_color, ray_at(ro, rd, t)) : 1.f;
-            out->weight[0] = out->weight[1] = out->weight[2] = col;
-            out->continued_weight[0] = out->continued_weight[1] = out->continued_weight[2] = col;
+            double col[3] = {1., 1., 1.};
+            if (m->P.mean_color.enabled) ramp_vec_of(&m->P.mean_color, ray_at(ro, rd, t), col);
+            for (int c = 0; c < 3; ++c) out->weight[c] = out->continued_weight[c] = (float)col[c];
         } else {
             v3f g = evaluate_gradient(&noise, v3f_of(ray_at(ro, rd, t)), (float)t, dir, state.info);
             aniso = v3d_of(g);
@@ -1701,20 +1863,20 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
     if (params->correlation_context < 0 || params->correlation_context > 3) return fail("invalid correlation context");
     if (params->scheme_1d < 0 || params->scheme_1d > 2) return fail("invalid sparse conv sampling scheme");
     if (!(params->impulse_density >= 0.f)) return fail("invalid impulse_density");
-    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > 3)) return fail("invalid ls ramp type");
-    if ((params->var.enabled && (params->var.type < 0 || params->var.type > 3)) || (params->mean_color.enabled && (params->mean_color.type < 0 || params->mean_color.type > 3)) ||
-        (params->mean_emission.enabled && (params->mean_emission.type < 0 || params->mean_emission.type > 3)))
+    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > GPIS_NOISE_RUST)) return fail("invalid ls ramp type");
+    if ((params->var.enabled && (params->var.type < 0 || params->var.type > GPIS_NOISE_RUST)) || (params->mean_color.enabled && (params->mean_color.type < 0 || params->mean_color.type > GPIS_NOISE_RUST)) ||
+        (params->mean_emission.enabled && (params->mean_emission.type < 0 || params->mean_emission.type > GPIS_NOISE_RUST)))
         return fail("invalid procedural noise type");
     if (params->var.enabled && !params->nonstationary) return fail("a var field needs the proc_nonstationary wrapper");
     if (params->aniso_field.enabled) {
-        if (params->aniso_field.type < 0 || params->aniso_field.type > 3) return fail("invalid procedural noise type");
+        if (params->aniso_field.type < 0 || params->aniso_field.type > GPIS_NOISE_RUST) return fail("invalid procedural noise type");
         if (!params->nonstationary) return fail("an aniso field needs the proc_nonstationary wrapper");
         if (params->sampling_1d) return fail("an aniso field is built for 3D sampling only");
     }
     if (params->kernel_type < 0 || params->kernel_type > 3) return fail("invalid kernel type");
     if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
-        if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 2.5f)
-            return fail("Matern kernel: v must be 0.5 or 2.5 (1.5 needs Boost's cyl_bessel_k)");
+        if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 1.5f && params->matern_v != 2.5f)
+            return fail("Matern kernel: v must be 0.5, 1.5 or 2.5");
         if (params->isotropic_3d_sampling || params->sampling_1d || params->nonstationary || params->correlation_context == GPIS_CTX_RENEWAL_PLUS)
             return fail("Matern / Gabor kernels: world-space 3D sampling with context none / global / renewal only");
     }
@@ -1769,6 +1931,8 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
         double mx = P->ls_max > P->ls_min ? P->ls_max : P->ls_min;
         if (P->ls_ramp_type == GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT)
             mx = mx * (P->ls_max2 > P->ls_min2 ? P->ls_max2 : P->ls_min2);
+        if (P->ls_ramp_type == GPIS_NOISE_SANDSTONE || P->ls_ramp_type == GPIS_NOISE_RUST)
+            mx = 1.;                                         /* GPF.cpp:130-137 */
         m->ls_maxval = (float)mx;
     }
     /* prepareForRender, GPM.cpp:152-158 */
@@ -2003,12 +2167,14 @@ int oracle_mean_color_emission(oracle_medium *m, size_t n, const double *p3, flo
     for (size_t i = 0; i < n; ++i) {
         v3d p = {p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]};
         if (color3) {
-            float c = m->P.mean_color.enabled ? (float)ramp_of(&m->P.mean_color, p) : 1.f;
-            color3[3 * i] = color3[3 * i + 1] = color3[3 * i + 2] = c;
+            double c[3] = {1., 1., 1.};
+            if (m->P.mean_color.enabled) ramp_vec_of(&m->P.mean_color, p, c);
+            for (int k = 0; k < 3; ++k) color3[3 * i + k] = (float)c[k];
         }
         if (emission3) {
-            float e = m->P.mean_emission.enabled ? (float)ramp_of(&m->P.mean_emission, p) : 0.f;
-            emission3[3 * i] = emission3[3 * i + 1] = emission3[3 * i + 2] = e;
+            double e[3] = {0., 0., 0.};
+            if (m->P.mean_emission.enabled) ramp_vec_of(&m->P.mean_emission, p, e);
+            for (int k = 0; k < 3; ++k) emission3[3 * i + k] = (float)e[k];
         }
     }
     return GPIS_OK;
@@ -2602,3 +2768,5 @@ void oracle_eig_invcov_scale(const float *m, float globalScale, float localScale
     for (int i = 0; i < 9; ++i) A[i] *= 0.5f;
     memcpy(o, A, sizeof A);
 }
+/* test surface: the Bessel functions of the Matern v = 3/2 kernel */
+void oracle_bessel_k01(double x, double *k0, double *k1) { bessel_k01(x, k0, k1); }

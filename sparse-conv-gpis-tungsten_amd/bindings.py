@@ -267,7 +267,8 @@ class GpisLib:
         "gpis_sample_distance_batch", "gpis_transmittance_batch", "gpis_eval_value_batch",
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
         "gpis_xxhash32_batch", "gpis_pcg32_stream_batch", "gpis_mean_color_emission_batch", "gpis_mean_color_emission_host",
-        "gpis_fs_sample_distance_batch", "gpis_fs_transmittance_batch",
+        "gpis_fs_sample_distance_batch", "gpis_fs_transmittance_batch", "gpis_fs_linalg_batch",
+        "gpis_fs_sample_distance_host", "gpis_fs_transmittance_host",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
@@ -307,6 +308,9 @@ class GpisLib:
         L.gpis_nee_pdf_batch.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_nee_grad_batch.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_mean_color_emission_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+        L.gpis_fs_linalg_batch.argtypes = [vp, i32, i32, sz, vp, vp, vp, vp]
+        L.gpis_fs_sample_distance_host.argtypes = [vp, sz, vp, vp, vp]
+        L.gpis_fs_transmittance_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_mean_color_emission_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_xxhash32_batch.argtypes = [vp, sz, i32, vp, vp, vp]
         L.gpis_pcg32_stream_batch.argtypes = [vp, sz, vp, u32, vp, vp]
@@ -424,6 +428,26 @@ class Medium:
         st = d_st.cpu().numpy().view(FS_STATE).copy()
         raw = d_out.cpu().numpy()
         return (raw[:n * SEG_OUT.itemsize].view(SEG_OUT).copy() if want_out else raw[:n].copy()), st
+
+    FS_OPS = {"eigh": 0, "norm_transform": 1, "pinv": 2}
+
+    def fs_linalg(self, op, mats):
+        """Test surface: the function-space path's eigen-solver / normTransform / pseudo-inverse on a stack of matrices
+        (count, n, n), numpy convention mats[k][i, j]; returns the result stack (and the eigenvalues for "eigh")."""
+        import torch
+        mats = np.asarray(mats, dtype=np.float64)
+        count, n = mats.shape[0], mats.shape[1]
+        colmajor = np.ascontiguousarray(np.transpose(mats, (0, 2, 1)))        # column-major storage of every matrix
+        dev = torch.device("cuda", self.device)
+        d_in = torch.from_numpy(colmajor.reshape(-1)).to(dev)
+        d_out = torch.zeros_like(d_in)
+        d_w = torch.zeros(count * n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        self.L.check(self.L.lib.gpis_fs_linalg_batch(self.h, self.FS_OPS[op], n, count, ctypes.c_void_p(d_in.data_ptr()), ctypes.c_void_p(d_out.data_ptr()),
+                                                     ctypes.c_void_p(d_w.data_ptr()), None), "gpis_fs_linalg_batch")
+        torch.cuda.synchronize(dev)
+        out = np.transpose(d_out.cpu().numpy().reshape(count, n, n), (0, 2, 1)).copy()
+        return (out, d_w.cpu().numpy().reshape(count, n)) if op == "eigh" else out
 
     def fs_sample_distance(self, rays, states):
         return self._fs_call("gpis_fs_sample_distance_batch", rays, states, True)

@@ -40,6 +40,7 @@ struct DevRamp {
     int32_t enabled, type;
     double scale, offset, log_min2, log_max2;        // first ramp: clamp(coord * scale + offset), lerp of log(min^2), log(max^2)
     double scale2, offset2, log2_min2, log2_max2;    // second ramp (bottom_top_left_right)
+    double vmin, vmax;                               // "min", "max" as given: the scalar sandstone / rust noises lerp between them
 };
 GPIS_DEV double ramp_unit(double coord, double scale, double offset, double la, double lb)
 {
@@ -53,6 +54,7 @@ struct DevModel {
     int32_t single_realization, iso3d, sampling_1d, correlation_xy, ctx;
     int32_t activate_conditioning, scheme_1d_eff, multi_res, nonstationary, multi_resolution_grid;
     int32_t use_aniso_mtx, surf_vol_phase_separate, has_mean_additional, absorption_only, max_bounces;
+    int32_t fbm_noise;            // some procedural field is a sandstone / rust noise: only the all-features path instance evaluates those
     float surf_vol_phase_amp_thresh;
     uint32_t seed, n_impulses, min_step;
     float step_size, impulse_density, sigma;
@@ -217,6 +219,7 @@ GPIS_DEV float expf_glibc(float x)
 struct V3 { float x, y, z; };
 struct V3d { double x, y, z; };
 struct V4 { float v, gx, gy, gz; };
+struct Mat9 { float m[9]; };   // a 3x3 kernel matrix passed by value (registers) to an out-of-line function
 
 GPIS_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 // ProceduralNoise::operator() / ProceduralNoiseVec::operator() (one component), GPF.cpp:43-103, _const = 1
@@ -229,6 +232,165 @@ GPIS_DEV double ramp_eval(const DevRamp &R, V3d p)
     }
     double coord = R.type == GPIS_RAMP_BOTTOM_TOP ? p.y : (R.type == GPIS_RAMP_LEFT_RIGHT ? p.x : p.z);
     return ramp_unit(coord, R.scale, R.offset, R.log_min2, R.log_max2) - 1.0;
+}
+// ---- "sandstone" / "rust": fbm over 3D simplex noise, math/SdfFunctions.cpp:199-296 (oracle: sdf_random3 / sdf_simplex3d /
+// sdf_fbm, pinned bit for bit against the reference's SdfFunctions.cpp).  Here `sin` and `sqrt` are ocml's: the hash
+// fract(512 * float(4096 sin(.))) absorbs a last-bit difference of the double sine unless it crosses a float rounding
+// boundary, so values agree with the CPU except at isolated points (tolerance stated in the tests).  Not inlined: only the
+// all-features instance of the path calls them, from cold code.
+static __device__ __attribute__((noinline)) float sdf_simplex3d(float px, float py, float pz)
+{
+    auto dot3 = [](float ax, float ay, float az, float bx, float by, float bz) { float r = ax * bx; r += ay * by; r += az * bz; return r; };
+    auto random3 = [&](float cx, float cy, float cz, float &rx, float &ry, float &rz) {        // SdfFunctions.cpp:199-208
+        float j = (float)(4096.0 * sin((double)dot3(cx, cy, cz, 17.0f, 59.4f, 15.0f)));
+        double v;
+        v = 512.0 * (double)j; rz = (float)(v - floor(v));
+        j = (float)((double)j * .125);
+        v = 512.0 * (double)j; rx = (float)(v - floor(v));
+        j = (float)((double)j * .125);
+        v = 512.0 * (double)j; ry = (float)(v - floor(v));
+        rx = rx - 0.5f; ry = ry - 0.5f; rz = rz - 0.5f;
+    };
+    const float F3 = 0.3333333f, G3 = 0.1666667f;
+    const float pf = dot3(px, py, pz, F3, F3, F3);
+    const float sx = floorf(px + pf), sy = floorf(py + pf), sz = floorf(pz + pf);
+    const float sg = dot3(sx, sy, sz, G3, G3, G3);
+    const float x = (px - sx) + sg, y = (py - sy) + sg, z = (pz - sz) + sg;
+    const float ex = (x - y) < 0.0f ? 0.f : 1.f, ey = (y - z) < 0.0f ? 0.f : 1.f, ez = (z - x) < 0.0f ? 0.f : 1.f;
+    const float i1x = ex * (1.0f - ez), i1y = ey * (1.0f - ex), i1z = ez * (1.0f - ey);
+    const float i2x = 1.0f - ez * (1.0f - ex), i2y = 1.0f - ex * (1.0f - ey), i2z = 1.0f - ey * (1.0f - ez);
+    const float g2 = 2.0f * G3, g3 = 3.0f * G3;
+    const float x1 = (x - i1x) + G3, y1 = (y - i1y) + G3, z1 = (z - i1z) + G3;
+    const float x2 = (x - i2x) + g2, y2 = (y - i2y) + g2, z2 = (z - i2z) + g2;
+    const float x3 = (x - 1.0f) + g3, y3 = (y - 1.0f) + g3, z3 = (z - 1.0f) + g3;
+    float w[4] = {dot3(x, y, z, x, y, z), dot3(x1, y1, z1, x1, y1, z1), dot3(x2, y2, z2, x2, y2, z2), dot3(x3, y3, z3, x3, y3, z3)}, d[4];
+    for (int i = 0; i < 4; ++i) { const float t = 0.6f - w[i]; w[i] = t < 0.0f ? 0.0f : t; }
+    float rx, ry, rz;
+    random3(sx, sy, sz, rx, ry, rz); d[0] = dot3(rx, ry, rz, x, y, z);
+    random3(sx + i1x, sy + i1y, sz + i1z, rx, ry, rz); d[1] = dot3(rx, ry, rz, x1, y1, z1);
+    random3(sx + i2x, sy + i2y, sz + i2z, rx, ry, rz); d[2] = dot3(rx, ry, rz, x2, y2, z2);
+    random3(sx + 1.0f, sy + 1.0f, sz + 1.0f, rx, ry, rz); d[3] = dot3(rx, ry, rz, x3, y3, z3);
+    for (int i = 0; i < 4; ++i) { w[i] *= w[i]; w[i] *= w[i]; d[i] *= w[i]; }
+    float r = d[0] * 52.0f; r += d[1] * 52.0f; r += d[2] * 52.0f; r += d[3] * 52.0f;
+    return r;
+}
+static __device__ __attribute__((noinline)) double sdf_fbm(double ux, double uy, double uz, int octaves)     // SdfFunctions.cpp:276-296
+{
+    const float gain = 0.65f, lacunarity = 2.1042f;
+    float total, frequency = 0.5f, amplitude = gain;
+    const float fx = (float)(ux * 5.0), fy = (float)(uy * 5.0), fz = (float)(uz * 5.0);
+    total = sdf_simplex3d(fx, fy, fz);
+    for (int i = 0; i < octaves; i++) {
+        total += sdf_simplex3d(fx * frequency, fy * frequency, fz * frequency) * amplitude;
+        frequency *= lacunarity;
+        amplitude *= gain;
+    }
+    total = (float)(((double)total + 2.0) / 4.0);
+    return (double)total;
+}
+GPIS_DEV double sdf_clamp01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+GPIS_DEV double sdf_sandstone_f(V3d p, int oct)                 // the nested fbm of GPF.cpp:72-73, 106-107
+{
+    const double x = p.x * 0.3, y = p.y * 0.3, z = p.z * 0.3;
+    const double f1 = sdf_fbm(x, y, z, oct);
+    const double f2 = sdf_fbm(x + f1, y + f1, z + f1, oct);
+    return sdf_fbm(x + f2, y + f2, z + f2, oct);
+}
+GPIS_DEV double sdf_rust_f(V3d p, int oct, double sign)         // GPF.cpp:80-81 (sign -1), 114-115 (sign +1)
+{
+    const double x = p.x * 2.0, y = p.y * 2.0, z = p.z * 2.0;
+    const double a = sdf_fbm(x * .1, y * .1, z * .1, oct) * 0.4;
+    const double b = sdf_fbm(x + a, y + a, z + a, oct);
+    const double c = sdf_fbm(x * 25., y * 25., z * 25., oct) * 0.1;
+    double v = sign < 0.0 ? b - c : b + c;
+    v = sdf_clamp01((v - 0.4) / (0.6 - 0.4));                   // smoothStep(0.4, 0.6, .), MathUtil.hpp:107-112
+    return v * v * (3.0 - 2.0 * v);
+}
+// the sandstone / rust branches as ONE out-of-line call per use (the all-features instance inlines the evaluator at many sites)
+static __device__ __attribute__((noinline)) double field_scalar_fbm(int type, double vmin, double vmax, double x, double y, double z)
+{
+    const V3d p{x, y, z};
+    const double t = type == GPIS_NOISE_SANDSTONE ? sdf_clamp01(sqrt((sdf_sandstone_f(p, 2) * 1.9) * 1.2) - 0.35) : sdf_clamp01(sdf_rust_f(p, 2, -1.0));
+    return vmin * (1.0 - t) + vmax * t;                            // lerp(_min, _max, .)
+}
+static __device__ __attribute__((noinline)) V3d field_vec_fbm(int type, double x, double y, double z)
+{
+    const V3d p{x, y, z};
+    if (type == GPIS_NOISE_SANDSTONE) {
+        const double f = sdf_sandstone_f(p, 10);
+        return V3d{sdf_clamp01((sqrt((f * 1.9) * 1.2) - 0.35) * 0.2), sdf_clamp01((sqrt((f * 0.7) * 1.2) - 0.35) * 0.2),
+                   sdf_clamp01((sqrt((f * 0.25) * 1.2) - 0.35) * 0.2)};
+    }
+    const double f = sdf_rust_f(p, 10, 1.0);
+    return V3d{0.278 * (1.0 - f) + 1. * f, 0.212 * (1.0 - f) + 1. * f, 0.141 * (1.0 - f) + 1. * f};
+}
+// ProceduralNoise::operator() (scalar fields "var", "aniso"), GPF.cpp:53-85
+GPIS_DEV double field_scalar(const DevRamp &R, V3d p, bool fbm_possible)
+{
+    if (fbm_possible && R.type >= GPIS_NOISE_SANDSTONE)
+        return field_scalar_fbm(R.type, R.vmin, R.vmax, p.x, p.y, p.z);
+    return ramp_eval(R, p);
+}
+// ProceduralNoiseVec::operator() (vector fields "ls", mean "color" / "emission"), GPF.cpp:87-120
+GPIS_DEV void field_vec(const DevRamp &R, V3d p, bool fbm_possible, double out[3])
+{
+    if (fbm_possible && R.type >= GPIS_NOISE_SANDSTONE) {
+        const V3d v = field_vec_fbm(R.type, p.x, p.y, p.z);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z;
+        return;
+    }
+    out[0] = out[1] = out[2] = ramp_eval(R, p);
+}
+// Modified Bessel functions of the second kind K0(x), K1(x), x > 0, for the Matern v = 3/2 splatting kernel (GPF.cpp:1053-1056,
+// 1071-1074 call boost::math::cyl_bessel_k, which is neither vendored nor installed: PARITY UNPINNED VS BOOST; the same code as
+// the oracle's bessel_k01, which tests/ check against the Wronskian and scipy to 1e-14).  x <= 2: ascending series; x > 2: Steed's
+// algorithm on the continued fraction CF2.  Not inlined: cold code of the all-features path instance.
+static __device__ __attribute__((noinline)) void bessel_k01(double x, double *k0, double *k1)
+{
+    const double EULER = 0.57721566490153286061;
+    if (x <= 2.0) {
+        const double q = 0.25 * x * x, lg = log(0.5 * x);
+        double term0 = 1.0, i0 = 1.0, s0 = 0.0, hk = 0.0;           /* term0 = q^k / (k!)^2 */
+        double term1 = 1.0, i1s = 1.0, s1 = 1.0 - 2.0 * EULER;       /* term1 = q^k / (k! (k+1)!), s1 = sum (psi(k+1) + psi(k+2)) term1 */
+        double hk1 = 1.0;                                            /* H_{k+1} */
+        for (int k = 1; k < 40; ++k) {
+            term0 *= q / ((double)k * (double)k);
+            hk += 1.0 / (double)k;
+            i0 += term0;
+            s0 += term0 * hk;
+            term1 *= q / ((double)k * (double)(k + 1));
+            hk1 += 1.0 / (double)(k + 1);
+            i1s += term1;
+            s1 += term1 * ((hk - EULER) + (hk1 - EULER));            /* psi(k+1) = H_k - g */
+            if (term0 < 1e-18 * i0) break;
+        }
+        *k0 = -(lg + EULER) * i0 + s0;
+        *k1 = 1.0 / x + lg * (0.5 * x * i1s) - 0.25 * x * s1;
+        return;
+    }
+    {
+        double b = 2.0 * (1.0 + x), d = 1.0 / b, h = d, delh = d, q1 = 0.0, q2 = 1.0;
+        const double a1 = 0.25;
+        double qq = a1, c = a1, a = -a1, s = 1.0 + qq * delh;
+        for (int i = 2; i <= 500; ++i) {
+            a -= 2.0 * (double)(i - 1);
+            c = -a * c / (double)i;
+            const double qnew = (q1 - b * q2) / a;
+            q1 = q2; q2 = qnew;
+            qq += c * qnew;
+            b += 2.0;
+            d = 1.0 / (b + a * d);
+            delh = (b * d - 1.0) * delh;
+            h += delh;
+            const double dels = qq * delh;
+            s += dels;
+            if (fabs(dels / s) < 1e-17) break;
+        }
+        h = a1 * h;
+        const double rk0 = sqrt(3.14159265358979323846 / (2.0 * x)) * exp(-x) / s;
+        *k0 = rk0;
+        *k1 = rk0 * (x + 0.5 - h) / x;
+    }
 }
 GPIS_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 GPIS_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -595,6 +757,8 @@ GPIS_DEV double lerp_d(double a, double b, double ratio) { return a * (1.0 - rat
 // generic: every flag read at run time.  Its names are visible in gpis through a using-directive
 // (not an inline namespace: ADL must not see them from inside the specialised namespaces).
 #define GPIS_PATH_NS generic
+#define GPIS_PATH_OUTLINE_NOISE3D 1
+#define GPIS_FLAG_fbm_noise(M) ((M).fbm_noise != 0)
 #define GPIS_FLAG_other_kernels(M) ((M).kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL)
 #define GPIS_FLAG_aniso_field(M) ((M).aniso.enabled)
 #define GPIS_FLAG_sampling_1d(M) ((M).sampling_1d)
@@ -607,6 +771,7 @@ GPIS_DEV double lerp_d(double a, double b, double ratio) { return a * (1.0 - rat
 
 // 1D sampling along the ray (config C2)
 #define GPIS_PATH_NS spec_1d
+#define GPIS_FLAG_fbm_noise(M) 0
 #define GPIS_FLAG_other_kernels(M) 0
 #define GPIS_FLAG_aniso_field(M) 0
 #define GPIS_FLAG_sampling_1d(M) 1
@@ -618,6 +783,7 @@ GPIS_DEV double lerp_d(double a, double b, double ratio) { return a * (1.0 - rat
 
 // 3D sampling, stationary kernel (config C0 and its per-path variants, C1 without the fast path)
 #define GPIS_PATH_NS spec_3d
+#define GPIS_FLAG_fbm_noise(M) 0
 #define GPIS_FLAG_other_kernels(M) 0
 #define GPIS_FLAG_aniso_field(M) 0
 #define GPIS_FLAG_sampling_1d(M) 0
@@ -629,6 +795,7 @@ GPIS_DEV double lerp_d(double a, double b, double ratio) { return a * (1.0 - rat
 
 // 3D sampling, non-stationary length scale on the multi-resolution grid (config C3)
 #define GPIS_PATH_NS spec_3d_multires
+#define GPIS_FLAG_fbm_noise(M) 0
 #define GPIS_FLAG_other_kernels(M) 0
 #define GPIS_FLAG_aniso_field(M) 0
 #define GPIS_FLAG_sampling_1d(M) 0

@@ -91,6 +91,107 @@ GPIS_DEV double fs_wave_max(double v)
     return v;
 }
 
+// ---- the reduction orders of the reference's Eigen build (vendored Eigen 3.4.90, SSE2 packets of two doubles, no FMA).  A
+// vectorised sum is not the ascending-index sum; these helpers add in the order Eigen's kernels add (restated and pinned bit for
+// bit against the reference's Eigen in oracle/gpis_fs_oracle.inc: eig_redux_prod, eig_gemv_row_dot, eig_symv_lower,
+// eig_gemm_dot, eig_llt), so the factorisations below produce the reference's bits, not merely its values.
+// DenseBase::redux on an expression without direct access (squaredNorm, dot), Core/Redux.h:321-375 with alignedStart = 0
+GPIS_DEV double fs_redux_prod(const double *a, const double *b, int n)
+{
+    const int n2 = (n / 2) * 2, n4 = (n / 4) * 4;
+    double res;
+    if (n2) {
+        double p0a = a[0] * b[0], p0b = a[1] * b[1];
+        if (n2 > 2) {
+            double p1a = a[2] * b[2], p1b = a[3] * b[3];
+            for (int i = 4; i < n4; i += 4) {
+                p0a += a[i] * b[i]; p0b += a[i + 1] * b[i + 1];
+                p1a += a[i + 2] * b[i + 2]; p1b += a[i + 3] * b[i + 3];
+            }
+            p0a += p1a; p0b += p1b;
+            if (n2 > n4) { p0a += a[n4] * b[n4]; p0b += a[n4 + 1] * b[n4 + 1]; }
+        }
+        res = p0a + p0b;
+        for (int i = n2; i < n; ++i) res += a[i] * b[i];
+    } else {
+        res = a[0] * b[0];
+        for (int i = 1; i < n; ++i) res += a[i] * b[i];
+    }
+    return res;
+}
+// general_matrix_vector_product, RowMajor (GeneralMatrixVector.h:330-520): one packet accumulator over the pairs, its lanes, the tail
+GPIS_DEV double fs_gemv_row_dot(const double *a, const double *b, int n)
+{
+    const int n2 = (n / 2) * 2;
+    double c0 = 0.0, c1 = 0.0;
+    for (int j = 0; j < n2; j += 2) { c0 = a[j] * b[j] + c0; c1 = a[j + 1] * b[j + 1] + c1; }
+    double cc = c0 + c1;
+    for (int j = n2; j < n; ++j) cc += a[j] * b[j];
+    return cc;
+}
+// gebp_kernel<double, mr = 4, nr = 4>: entry (i, j) of an R x C product of depth K — one accumulator over ascending k, except in
+// the "one packet" rows of the last half-filled row block and full 4-column panels, where even and odd k accumulate separately
+// over the peeled depth (GeneralBlockPanelKernel.h:1360-1445).  a / b: the K factors with strides sa / sb.
+GPIS_DEV double fs_gemm_dot(const double *a, int sa, const double *b, int sb, int K, int i, int j, int R, int C, bool kernel_call)
+{
+    const int r4 = (R / 4) * 4, r2 = r4 + ((R % 4) / 2) * 2, c4 = (C / 4) * 4;
+    if (i >= r4 && i < r2 && j < c4 && (kernel_call || R + C + K >= 20)) {
+        const int pk = (K / 8) * 8;
+        double c = 0.0, d = 0.0;
+        for (int k = 0; k < pk; k += 2) { c = a[k * sa] * b[k * sb] + c; d = a[(k + 1) * sa] * b[(k + 1) * sb] + d; }
+        c = c + d;
+        for (int k = pk; k < K; ++k) c = a[k * sa] * b[k * sb] + c;
+        return c;
+    }
+    double acc = 0.0;
+    #pragma unroll 8
+    for (int k = 0; k < K; ++k) acc += a[k * sa] * b[k * sb];
+    return acc;
+}
+// selfadjoint_matrix_vector_product<double, ColMajor, Lower> (SelfadjointMatrixVector.h:43-154), row r of res = alpha * B * v for
+// the size x size symmetric matrix whose lower triangle is B (column-major, leading dimension lda), res zero before the call:
+// two columns per pass, packet loops whose peeling depends on the 16-byte alignment of res (res_odd).  The kernel adds the terms
+// of columns j < r to res[r] pair by pair, then the diagonal, and LAST alpha x (the column sum over i > r, itself split into a
+// scalar part and two packet lanes); the last <= 9 columns go one at a time.
+GPIS_DEV double fs_symv_row(const double *B, int lda, const double *v, int size, double alpha, int res_odd, int r)
+{
+    const int bound = (size - 8 > 0 ? size - 8 : 0) & ~1;
+    const int aE = size - ((size - res_odd) & 1);
+    double res = 0.0;
+    const int npair = r < bound ? (r & ~1) : bound;
+    for (int c = 0; c < npair; c += 2) {
+        const double t0 = alpha * v[c], t1 = alpha * v[c + 1];
+        const double a0 = B[c * lda + r], a1 = B[(c + 1) * lda + r];
+        if (r >= c + 2 + res_odd && r < aE) res = a0 * t0 + (a1 * t1 + res);
+        else res += a0 * t0 + a1 * t1;
+    }
+    const double *col = B + r * lda;
+    if (r < bound) {
+        const int jr = r & ~1;
+        const double t0 = alpha * v[jr], t1 = alpha * v[jr + 1];
+        if (r == jr) {
+            res += col[r] * t0;
+        } else {
+            res += col[r] * t1;
+            res += B[jr * lda + r] * t0;
+        }
+        const int aS = jr + 2 + res_odd;
+        double t = 0.0, pa = 0.0, pb = 0.0;
+        int i = r + 1;
+        for (; i < aS; ++i) t += col[i] * v[i];
+        for (; i < aE; i += 2) { pa = col[i] * v[i] + pa; pb = col[i + 1] * v[i + 1] + pb; }
+        for (; i < size; ++i) t += col[i] * v[i];
+        res += alpha * (t + (pa + pb));
+    } else {
+        for (int j = bound; j < r; ++j) res += B[j * lda + r] * (alpha * v[j]);
+        res += col[r] * (alpha * v[r]);
+        double t2 = 0.0;
+        for (int i = r + 1; i < size; ++i) t2 += col[i] * v[i];
+        res += alpha * t2;
+    }
+    return res;
+}
+
 // Eigen::SelfAdjointEigenSolver<MatrixXd>::compute on the n x n column-major matrix A (lower triangle read): on return the
 // columns of A are the eigenvectors and L.w the eigenvalues, ascending.  Every lane runs the scalar recurrences on the same
 // data; lane 0 stores them.
@@ -113,8 +214,7 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
     { FS_T0();
     for (int i = 0; i < n - 1; ++i) {                       // tridiagonalization_inplace, Tridiagonalization.h:352-383
         const int rs = n - i - 1;
-        double tailSq = 0.0;
-        for (int k = i + 2; k < n; ++k) tailSq += E(k, i) * E(k, i);
+        const double tailSq = rs == 1 ? 0.0 : fs_redux_prod(&E(i + 2, i), &E(i + 2, i), rs - 1);     // tail.squaredNorm()
         const double c0 = E(i + 1, i);
         double h, beta;
         FS_SYNC();
@@ -129,18 +229,11 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
         }
         if (lane == 0) E(i + 1, i) = 1.0;
         FS_SYNC();
-        for (int r = lane; r < rs; r += 64) {
-            double s = 0.0;
-            #pragma unroll 8
-            for (int c = 0; c < rs; ++c) {
-                const double a = r >= c ? E(i + 1 + r, i + 1 + c) : E(i + 1 + c, i + 1 + r);
-                s += a * (h * E(i + 1 + c, i));
-            }
-            L.hv[r] = s;
-        }
+        // hCoeffs.tail(rs) = selfadjointView<Lower>(bottomRight) * (h v): h is the kernel's alpha, &hCoeffs[i] its destination
+        for (int r = lane; r < rs; r += 64)
+            L.hv[r] = fs_symv_row(&E(i + 1, i + 1), n, &E(i + 1, i), rs, h, i & 1, r);
         FS_SYNC();
-        double dotp = 0.0;
-        for (int r = 0; r < rs; ++r) dotp += L.hv[r] * E(i + 1 + r, i);
+        const double dotp = fs_redux_prod(L.hv, &E(i + 1, i), rs);
         const double alpha = h * -0.5 * dotp;
         FS_SYNC();
         for (int r = lane; r < rs; r += 64) L.hv[r] += alpha * E(i + 1 + r, i);
@@ -176,12 +269,8 @@ GPIS_DEV void fs_eigh(FsLds &L, int n, double *A, int lane)
         if (cs == 1) {
             if (lane == 0) E(o, o) *= 1.0 - tau;
         } else if (tau != 0.0) {                            // applyHouseholderOnTheLeft, Householder.h:119-137
-            for (int c = lane; c < cs; c += 64) {
-                double s = 0.0;
-                #pragma unroll 8
-                for (int r = 1; r < cs; ++r) s += E(k + 1 + r, k) * E(o + r, o + c);
-                L.tmp[c] = s + E(o, o + c);
-            }
+            for (int c = lane; c < cs; c += 64)            // tmp = essential.adjoint() * bottom (row-major gemv); tmp += row(0)
+                L.tmp[c] = fs_gemv_row_dot(&E(o + 1, o + c), &E(k + 2, k), cs - 1) + E(o, o + c);
             FS_SYNC();
             for (int c = lane; c < cs; c += 64) E(o, o + c) -= tau * L.tmp[c];
             for (int r = 1 + lane; r < cs; r += 64) {
@@ -313,13 +402,9 @@ GPIS_DEV void fs_pinv(FsLds &L, FsGlob &G, int n, int lane)
             U[k * n + i] = A[k * n + i] * sqrt(sp);
         }
     FS_SYNC();
-    for (int i = lane; i < n; i += 64)
-        for (int j = 0; j < n; ++j) {
-            double s = 0.0;
-            #pragma unroll 8
-            for (int k = 0; k < n; ++k) s += U[k * n + i] * U[k * n + j];
-            A[j * n + i] = s;
-        }
+    for (int i = lane; i < n; i += 64)                     // U * U.transpose(): a general matrix product
+        for (int j = 0; j < n; ++j)
+            A[j * n + i] = fs_gemm_dot(U + i, n, U + j, n, n, i, j, n, n, false);
     FS_SYNC();
     FS_T(4);
 }
@@ -335,19 +420,57 @@ GPIS_DEV void fs_norm_transform(FsLds &L, FsGlob &G, int n, int lane)
     bool ok = true;
     FS_T0();
 #define LL(i, j) T[(j) * n + (i)]
-    for (int k = 0; k < n; ++k) {                           // LLT (Cholesky/LLT.h): a pivot x <= 0 is the failure
-        double x = LL(k, k);
-        for (int j = 0; j < k; ++j) x -= LL(k, j) * LL(k, j);
-        if (x <= 0.0) { ok = false; break; }
-        x = sqrt(x);
-        FS_SYNC();
-        if (lane == 0) LL(k, k) = x;
-        for (int i = k + 1 + lane; i < n; i += 64) {
-            double s = LL(i, k);
-            #pragma unroll 8
-            for (int j = 0; j < k; ++j) s -= LL(i, j) * LL(k, j);
-            LL(i, k) = s / x;
+    // Eigen::LLT<MatrixXd, Lower> = llt_inplace (Cholesky/LLT.h:312-385): below 32 rows the unblocked loop, else blocks of 8
+    // columns — unblocked diagonal block, triangular solve of the panel below it in small panels of 4 columns, rank-8 update of the
+    // trailing matrix through gebp (oracle: eig_llt).  A pivot x <= 0 is the failure.  Lane = row.
+    const int bsz = n < 32 ? n : 8;
+    for (int k0 = 0; k0 < n && ok; k0 += bsz) {
+        const int bs = n - k0 < bsz ? n - k0 : bsz, rs = n - k0 - bs, o = k0 + bs;
+        for (int k = 0; k < bs; ++k) {                      // unblocked on rows / columns k0 .. k0 + bs - 1
+            const int kk = k0 + k;
+            double x = LL(kk, kk);
+            if (k > 0) {
+                double sq = LL(kk, k0) * LL(kk, k0);
+                for (int j = 1; j < k; ++j) sq += LL(kk, k0 + j) * LL(kk, k0 + j);
+                x -= sq;
+            }
+            if (x <= 0.0) { ok = false; break; }
+            x = sqrt(x);
+            FS_SYNC();
+            if (lane == 0) LL(kk, kk) = x;
+            for (int i = kk + 1 + lane; i < o; i += 64) {
+                double v = LL(i, kk);
+                if (k > 0) {                                // A21 -= A20 * A10.adjoint(): column-major gemv, alpha = -1
+                    double c = 0.0;
+                    for (int j = 0; j < k; ++j) c = LL(i, k0 + j) * LL(kk, k0 + j) + c;
+                    v = c * -1.0 + v;
+                }
+                LL(i, kk) = v / x;
+            }
+            FS_SYNC();
         }
+        if (!ok || rs <= 0) continue;
+        for (int i = lane; i < rs; i += 64) {               // A21 := A21 * A11^-T, one row per lane
+            for (int j2 = 0; j2 < bs; j2 += 4) {
+                const int pw = bs - j2 < 4 ? bs - j2 : 4;
+                if (j2 > 0)
+                    for (int c = 0; c < pw; ++c) {
+                        double acc = 0.0;
+                        for (int q = 0; q < j2; ++q) acc = LL(o + i, k0 + q) * LL(k0 + j2 + c, k0 + q) + acc;
+                        LL(o + i, k0 + j2 + c) = acc * -1.0 + LL(o + i, k0 + j2 + c);
+                    }
+                for (int c = 0; c < pw; ++c) {
+                    const int j = k0 + j2 + c;
+                    double v = LL(o + i, j);
+                    for (int c3 = 0; c3 < c; ++c3) v -= LL(o + i, k0 + j2 + c3) * LL(j, k0 + j2 + c3);
+                    LL(o + i, j) = v * (1.0 / LL(j, j));
+                }
+            }
+        }
+        FS_SYNC();
+        for (int i = lane; i < rs; i += 64)                 // A22.selfadjointView<Lower>().rankUpdate(A21, -1)
+            for (int j = 0; j <= i; ++j)
+                LL(o + i, o + j) = fs_gemm_dot(&LL(o + i, k0), n, &LL(o + j, k0), n, bs, i, j, rs, rs, true) * -1.0 + LL(o + i, o + j);
         FS_SYNC();
     }
     FS_SYNC();
@@ -432,13 +555,9 @@ GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, FsGlob &G, int n, int 
         FS_T(5); }
         fs_pinv(L, G, nc, lane);
         FS_T0();
-        for (int i = lane; i < nc; i += 64)
-            for (int j = 0; j < n; ++j) {
-                double acc = 0.0;
-                #pragma unroll 8
-                for (int k = 0; k < nc; ++k) acc += s11[k * nc + i] * s12[j * nc + k];
-                sol[j * nc + i] = acc;
-            }
+        for (int i = lane; i < nc; i += 64)                // pinv * s12: nc x n, depth nc
+            for (int j = 0; j < n; ++j)
+                sol[j * nc + i] = fs_gemm_dot(s11 + i, nc, s12 + j * nc, 1, nc, i, j, nc, n, false);
         for (int k = lane; k < nc; k += 64) G.resid[k] = G.cv[k] - fs_mean(M, G.cder[k], fs_v3(G.cpts[k]), deriv_dir);
         FS_SYNC();
         FS_T(6);
@@ -446,12 +565,8 @@ GPIS_DEV void fs_sample_cond(const DevModel &M, FsLds &L, FsGlob &G, int n, int 
             double acc = 0.0;
             for (int k = 0; k < nc; ++k) acc += sol[i * nc + k] * G.resid[k];
             G.mean[i] += acc;
-            for (int j = 0; j < n; ++j) {
-                double a2 = 0.0;
-                #pragma unroll 8
-                for (int k = 0; k < nc; ++k) a2 += sol[i * nc + k] * s12[j * nc + k];
-                S[j * n + i] -= a2;
-            }
+            for (int j = 0; j < n; ++j)                    // solved * s12: n x n, depth nc
+                S[j * n + i] -= fs_gemm_dot(sol + i * nc, 1, s12 + j * nc, 1, nc, i, j, n, n, false);
         }
         FS_SYNC();
         FS_T(7);
@@ -776,7 +891,7 @@ __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp
                         o.gp_id = state.last_gp_id; o.ok = 0;
                         finished = true;
                     } else {
-                        const float col = M.color.enabled ? (float)ramp_eval(M.color, ray_at(ro, rd, t)) : 1.f;
+                        const float col = M.color.enabled ? (float)ramp_eval(M.color, ray_at(ro, rd, t)) : 1.f;     // ramp noises (fs_check refuses a sandstone / rust colour here)
                         o.weight[0] = o.weight[1] = o.weight[2] = col;
                         o.continued_weight[0] = o.continued_weight[1] = o.continued_weight[2] = col;
                     }
@@ -808,6 +923,33 @@ __global__ void __launch_bounds__(64) k_fs_march(const DevModel *__restrict__ Mp
         o.aniso[0] = aniso.x; o.aniso[1] = aniso.y; o.aniso[2] = aniso.z;
         if (lane == 0) { outs[idx] = o; st->sampler_state = s.state; }
         FS_T(10);
+    }
+}
+
+// Test surface (gpis_fs_linalg_batch): the dense linear algebra of this path on caller-supplied matrices, one wave per matrix —
+// op 0: SelfAdjointEigenSolver (eigenvectors -> out, eigenvalues -> evals), 1: MultivariateNormalDistribution's normTransform
+// (LLT, else the eigen square root), 2: pseudo_inverse.  n x n column-major doubles; only +, -, *, / and sqrt run here, so the
+// results equal the CPU restatement's — and, through it, the reference's Eigen — bit for bit.
+GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_fs_linalg(int op, int n, size_t count, const double *__restrict__ in, double *__restrict__ out,
+                                                                double *__restrict__ evals, FsGlob *__restrict__ workspace)
+{
+    __shared__ FsLds L;
+    FsGlob &G = workspace[blockIdx.x];
+    const int lane = (int)threadIdx.x;
+    for (size_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const double *a = in + idx * (size_t)n * n;
+        double *o = out + idx * (size_t)n * n;
+        FS_SYNC();
+        double *dst = op == 1 ? G.B4 : L.B1;
+        for (int i = lane; i < n * n; i += 64) dst[i] = a[i];
+        FS_SYNC();
+        if (op == 0) fs_eigh(L, n, L.B1, lane);
+        else if (op == 1) fs_norm_transform(L, G, n, lane);
+        else fs_pinv(L, G, n, lane);
+        FS_SYNC();
+        for (int i = lane; i < n * n; i += 64) o[i] = L.B1[i];
+        if (op == 0 && evals)
+            for (int i = lane; i < n; i += 64) evals[idx * (size_t)n + i] = L.w[i];
     }
 }
 

@@ -109,6 +109,9 @@ struct gpis_medium {
     void *stage[5];
     size_t stage_bytes[5];
     std::mutex mu;
+    std::mutex fs_host_mu;   // serialises the function-space host entries, which own fs_stage[] end to end
+    void *fs_stage[3] = {nullptr, nullptr, nullptr};
+    size_t fs_stage_bytes[3] = {0, 0, 0};
     // optional per-kernel timing (gpis_set_profiling): event pairs around each march launch
     int batch_hint;          // gpis_set_batch_order: which form of the guided march the *_batch / *_host entries use
     // tuning options (gpis_set_option; defaults from the GPIS_* environment variables read ONCE in gpis_create)
@@ -132,10 +135,10 @@ struct gpis_medium {
     int persist_waves[8];    // cached occupancy * CUs per kernel instance; 0 = not queried yet
     int n_cus;
     bool profiling;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];
-    size_t events_used[2];
-    double prof_ms[2];
-    uint64_t prof_launches[2];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events[3];     // 0: sampleDistance, 1: transmittance, 2: the NEE driver's neePDF / neeGrad launches
+    size_t events_used[3];
+    double prof_ms[3];
+    uint64_t prof_launches[3];
 };
 
 static int ensure_stage(gpis_medium *m, int slot, size_t bytes)
@@ -262,6 +265,7 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
         const double a = mn + 1., b = mx + 1., a2 = mn2 + 1., b2 = mx2 + 1.;
         R.log_min2 = log(a * a); R.log_max2 = log(b * b);
         R.log2_min2 = log(a2 * a2); R.log2_max2 = log(b2 * b2);
+        R.vmin = mn; R.vmax = mx;
         return R;
     };
     M.ls = make_ramp(M.nonstationary, P.ls_ramp_type, P.ls_min, P.ls_max, P.ls_start, P.ls_end, P.ls_min2, P.ls_max2, P.ls_start2, P.ls_end2);
@@ -274,6 +278,14 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
                            P.mean_emission.min2, P.mean_emission.max2, P.mean_emission.start2, P.mean_emission.end2);
     if (P.ls_ramp_type == GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT)      // ProceduralNoiseVec::maxVal, GPF.cpp:124-138
         M.ls_maxval = (float)((P.ls_max > P.ls_min ? P.ls_max : P.ls_min) * (P.ls_max2 > P.ls_min2 ? P.ls_max2 : P.ls_min2));
+    if (P.ls_ramp_type == GPIS_NOISE_SANDSTONE || P.ls_ramp_type == GPIS_NOISE_RUST)
+        M.ls_maxval = 1.f;
+    {   // sandstone / rust anywhere: the launcher routes the medium to the all-features path instance (gpis_device.hpp: GPIS_FLAG_fbm_noise)
+        const DevRamp *fields[5] = {&M.ls, &M.var, &M.aniso, &M.color, &M.emission};
+        M.fbm_noise = 0;
+        for (const DevRamp *f : fields)
+            if (f->enabled && f->type >= GPIS_NOISE_SANDSTONE) M.fbm_noise = 1;
+    }
     const float base = 2.5f;
     M.log_base = logf(base);
     for (int l = kLevelMin; l <= kLevelMax; ++l) {
@@ -331,7 +343,7 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
             float mx = la[0] > la[1] ? la[0] : la[1];
             mx = mx > la[2] ? mx : la[2];
             M.radius_world = (float)(M.kernel_scale * 1.0f * sqrt(2) / 2 * mx);
-            iks = P.matern_v == 0.5 ? 2.0 * M_PI * l : M_PI * pow(l, 3) / (5 * sqrt(5));
+            iks = P.matern_v == 0.5 ? 2.0 * M_PI * l : (P.matern_v == 1.5 ? pow(M_PI * l, 3) / (24 * sqrt(3)) : M_PI * pow(l, 3) / (5 * sqrt(5)));      // GPF.cpp:1029-1046
         } else if (P.kernel_type == GPIS_KERNEL_GABOR_ANISO) {
             M.radius_world = (float)(M.kernel_scale * sqrt(2) / 2 * 1.0 / a);
             const float q = f / a;
@@ -399,12 +411,14 @@ __global__ void __launch_bounds__(256) k_mean_color_emission(const DevModel *__r
     const DevModel &M = *Mp;
     const V3d p{p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]};
     if (color3) {
-        const float c = M.color.enabled ? (float)ramp_eval(M.color, p) : 1.f;
-        color3[3 * i] = c; color3[3 * i + 1] = c; color3[3 * i + 2] = c;
+        double c[3] = {1., 1., 1.};
+        if (M.color.enabled) field_vec(M.color, p, true, c);
+        for (int k = 0; k < 3; ++k) color3[3 * i + k] = (float)c[k];
     }
     if (emission3) {
-        const float e = M.emission.enabled ? (float)ramp_eval(M.emission, p) : 0.f;
-        emission3[3 * i] = e; emission3[3 * i + 1] = e; emission3[3 * i + 2] = e;
+        double e[3] = {0., 0., 0.};
+        if (M.emission.enabled) field_vec(M.emission, p, true, e);
+        for (int k = 0; k < 3; ++k) emission3[3 * i + k] = (float)e[k];
     }
 }
 __global__ void k_xxhash32(size_t n, int arity, const uint32_t *__restrict__ w, uint32_t *__restrict__ out)
@@ -1000,22 +1014,22 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     if (!(params->impulse_density >= 0.f) || params->impulse_density > 4096.f) return set_err(GPIS_ERR_INVALID_ARG, "impulse_density out of range");
     if (params->mean.type < 0 || params->mean.type > 2 || (params->has_mean_additional && (params->mean_additional.type < 0 || params->mean_additional.type > 2)))
         return set_err(GPIS_ERR_INVALID_ARG, "invalid mean type");
-    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > 3)) return set_err(GPIS_ERR_INVALID_ARG, "invalid ls ramp type");
+    if (params->nonstationary && (params->ls_ramp_type < 0 || params->ls_ramp_type > GPIS_NOISE_RUST)) return set_err(GPIS_ERR_INVALID_ARG, "invalid ls noise type");
     {
         const gpis_ramp *ramps[3] = {&params->var, &params->mean_color, &params->mean_emission};
         for (const gpis_ramp *r : ramps)
-            if (r->enabled && (r->type < 0 || r->type > 3)) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type (sandstone / rust are outside the built scope)");
+            if (r->enabled && (r->type < 0 || r->type > GPIS_NOISE_RUST)) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type");
         if (params->var.enabled && !params->nonstationary) return set_err(GPIS_ERR_INVALID_ARG, "a \"var\" field needs the proc_nonstationary wrapper");
         if (params->aniso_field.enabled) {
-            if (params->aniso_field.type < 0 || params->aniso_field.type > 3) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type (sandstone / rust are outside the built scope)");
+            if (params->aniso_field.type < 0 || params->aniso_field.type > GPIS_NOISE_RUST) return set_err(GPIS_ERR_INVALID_ARG, "invalid procedural noise type");
             if (!params->nonstationary) return set_err(GPIS_ERR_INVALID_ARG, "an \"aniso\" field needs the proc_nonstationary wrapper");
             if (params->sampling_1d) return set_err(GPIS_ERR_INVALID_ARG, "an \"aniso\" field is built for 3D sampling only (GPF.cpp:1691-1727 are outside the built scope)");
         }
     }
     if (params->kernel_type < 0 || params->kernel_type > 3) return set_err(GPIS_ERR_INVALID_ARG, "invalid kernel type");
     if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
-        if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 2.5f)
-            return set_err(GPIS_ERR_UNSUPPORTED, "Matern kernel: v must be 0.5 or 2.5 (1.5 needs Boost's cyl_bessel_k, GPF.cpp:1055)");
+        if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 1.5f && params->matern_v != 2.5f)
+            return set_err(GPIS_ERR_UNSUPPORTED, "Matern kernel only implemented for v = 0.5, 1.5, 2.5! (GPF.cpp:1000)");
         if (params->isotropic_3d_sampling || params->sampling_1d || params->nonstationary || params->correlation_context == GPIS_CTX_RENEWAL_PLUS)
             return set_err(GPIS_ERR_UNSUPPORTED, "Matern / Gabor kernels: world-space 3D sampling with correlation context none / global / renewal only "
                                                  "(they define no isotropic transform, 1D kernel or second derivative, GPF.hpp:2002-2110)");
@@ -1062,7 +1076,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     }
     memset(&m->guide, 0, sizeof m->guide);
     m->profiling = false;
-    for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
+    for (int k = 0; k < 3; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
     memset(&m->fast, 0, sizeof m->fast);
     int st = build_model(*params, m->host_model, m->derived);
     if (st != GPIS_OK) { delete m; return st; }
@@ -1107,7 +1121,9 @@ extern "C" int gpis_destroy(gpis_medium *m)
     if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
     if (m->d_guide) (void)hipFree(m->d_guide);
     if (m->fs_ws) (void)hipFree(m->fs_ws);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 3; ++k)
+        if (m->fs_stage[k]) (void)hipFree(m->fs_stage[k]);
+    for (int k = 0; k < 3; ++k)
         for (auto &ev : m->events[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int i = 0; i < 5; ++i)
         if (m->stage[i]) (void)hipFree(m->stage[i]);
@@ -1277,7 +1293,7 @@ static int wave_march(gpis_medium *m, size_t n, const gpis_ray_in *rays, const u
 
 // ---- persistent march launch (per-path media) ---------------------------------------------------------------
 // the lattice sums of gpis_persist.inc have a diagonal kernel matrix: every medium except world-space 3D with a full anisoMtx
-static bool persist_supported(const DevModel &H) { return !H.aniso.enabled && (H.sampling_1d || H.iso3d || !H.use_aniso_mtx); }
+static bool persist_supported(const DevModel &H) { return !H.aniso.enabled && !H.fbm_noise && (H.sampling_1d || H.iso3d || !H.use_aniso_mtx); }
 // sideways (lane = impulse) evaluation pays while at most this many lanes of a wave have a job: lockstep costs
 // 27 n g instructions per round whatever the number of jobs, one sideways job ~20.6 cells x (c0 + c1 n)
 // (g = 61 generator, c0 = 135, c1 = 0.31: counted on the gfx950 ISA of these loops)
@@ -1297,7 +1313,8 @@ static int launch_persist(gpis_medium *m, PersistArgs a, hipStream_t s)
     if (a.n >= 0xFFFF0000ull) return set_err(GPIS_ERR_INVALID_ARG, "persistent march: batch too large for the 32-bit ray counter");
     a.solo_max = persist_solo_max(m);
     int inst = launch::INST_GENERIC;
-    if (H.sampling_1d) inst = launch::INST_1D;
+    if (H.fbm_noise) inst = launch::INST_GENERIC;          // sandstone / rust fields: all-features instance only
+    else if (H.sampling_1d) inst = launch::INST_1D;
     else if (H.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) inst = launch::INST_GENERIC;
     else if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid) inst = launch::INST_3D;
     else if (H.nonstationary && H.multi_res && H.multi_resolution_grid) inst = launch::INST_3D_MULTIRES;
@@ -1317,6 +1334,7 @@ static int launch_persist(gpis_medium *m, PersistArgs a, hipStream_t s)
 // the lane-per-ray instance whose compile-time flags equal the medium's
 static int lane_instance(const DevModel &H)
 {
+    if (H.fbm_noise) return launch::INST_GENERIC;           // sandstone / rust fields: all-features instance only
     if (H.sampling_1d) return launch::INST_1D;
     if (!H.nonstationary && !H.multi_res && !H.multi_resolution_grid && H.kernel_type == GPIS_KERNEL_SQUARED_EXPONENTIAL) return launch::INST_3D;
     if (H.nonstationary && H.multi_res && H.multi_resolution_grid && !H.aniso.enabled) return launch::INST_3D_MULTIRES;
@@ -1482,23 +1500,28 @@ static int fs_check(gpis_medium *m)
 {
     const DevModel &H = m->host_model;
     if (H.fs_n < 2 || H.fs_n > GPIS_FS_MAX_POINTS || !(H.fs_step >= 0) || H.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL || H.nonstationary ||
-        H.use_aniso_mtx || H.has_mean_additional)
-        return set_err(GPIS_ERR_INVALID_ARG, "function-space path: squared-exponential covariance, analytic mean, 2..64 sample points");
+        H.use_aniso_mtx || H.has_mean_additional || (H.color.enabled && H.color.type >= GPIS_NOISE_SANDSTONE))
+        return set_err(GPIS_ERR_INVALID_ARG, "function-space path: squared-exponential covariance, analytic mean (ramp colour), 2..64 sample points");
+    return GPIS_OK;
+}
+// 37 KB of LDS per workgroup: four one-wave workgroups (one per SIMD) are resident per CU and walk the batch; each owns one
+// slice of the L2-resident workspace
+static int fs_workspace(gpis_medium *m, unsigned &cap)
+{
+    cap = (unsigned)(m->n_cus > 0 ? m->n_cus : 256) * 4u;
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (m->fs_ws_blocks < cap) {
+        if (m->fs_ws) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(m->fs_ws); m->fs_ws = nullptr; m->fs_ws_blocks = 0; }
+        if (hipMalloc(&m->fs_ws, (size_t)cap * launch::fs_workspace_bytes_per_block()) != hipSuccess) { (void)hipGetLastError(); return set_err(GPIS_ERR_DEVICE, "function-space workspace allocation failed"); }
+        m->fs_ws_blocks = cap;
+    }
     return GPIS_OK;
 }
 static int fs_launch(bool want_sample, gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, uint8_t *visible, hipStream_t s)
 {
     HIP_TRY(hipSetDevice(m->device));
-    // 37 KB of LDS per workgroup: four one-wave workgroups (one per SIMD) are resident per CU and walk the batch
-    const unsigned cap = (unsigned)(m->n_cus > 0 ? m->n_cus : 256) * 4u;
-    {
-        std::lock_guard<std::mutex> lock(m->mu);
-        if (m->fs_ws_blocks < cap) {
-            if (m->fs_ws) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(m->fs_ws); m->fs_ws = nullptr; m->fs_ws_blocks = 0; }
-            if (hipMalloc(&m->fs_ws, (size_t)cap * launch::fs_workspace_bytes_per_block()) != hipSuccess) { (void)hipGetLastError(); return set_err(GPIS_ERR_DEVICE, "function-space workspace allocation failed"); }
-            m->fs_ws_blocks = cap;
-        }
-    }
+    unsigned cap = 0;
+    if (int st = fs_workspace(m, cap)) return st;
     const unsigned grid = (unsigned)(n < cap ? n : cap);
     launch::fs_march(want_sample, grid, m->d_model, n, rays, states, out, visible, m->fs_ws, s);
     return launch_check("k_fs_march");
@@ -1506,6 +1529,16 @@ static int fs_launch(bool want_sample, gpis_medium *m, size_t n, const gpis_ray_
 #ifdef GPIS_FS_PROF
 extern "C" int gpis_fs_prof_read(unsigned long long *out16, int reset) { return launch::fs_prof_read(out16, reset); }
 #endif
+extern "C" int gpis_fs_linalg_batch(gpis_medium *m, int op, int n, size_t count, const double *in, double *out, double *evals, void *stream)
+{
+    CHECK_ARGS(m && op >= GPIS_FS_OP_EIGH && op <= GPIS_FS_OP_PINV && n >= 1 && n <= GPIS_FS_MAX_CTX && (count == 0 || (in && out)));
+    if (count == 0) return GPIS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    unsigned cap = 0;
+    if (int st = fs_workspace(m, cap)) return st;
+    launch::fs_linalg((unsigned)(count < cap ? count : cap), op, n, count, in, out, evals, m->fs_ws, (hipStream_t)stream);
+    return launch_check("k_fs_linalg");
+}
 extern "C" int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && states && out)));
@@ -1519,6 +1552,43 @@ extern "C" int gpis_fs_transmittance_batch(gpis_medium *m, size_t n, const gpis_
     if (int st = fs_check(m)) return st;
     if (n == 0) return GPIS_OK;
     return fs_launch(false, m, n, rays, states, nullptr, visible, (hipStream_t)stream);
+}
+// host-pointer forms of the two function-space entries: one staging round trip per call (stage[0..2] are shared by the
+// host conveniences of this handle, so the whole call holds the handle's host mutex; the workspace has its own lock)
+static int fs_host(gpis_medium *m, bool want_sample, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, void *out)
+{
+    if (int st = fs_check(m)) return st;
+    if (n == 0) return GPIS_OK;
+    std::lock_guard<std::mutex> lock(m->fs_host_mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t out_rec = want_sample ? sizeof(gpis_seg_out) : 1;
+    const size_t need[3] = {n * sizeof(gpis_ray_in), n * sizeof(gpis_fs_state), n * out_rec};
+    for (int k = 0; k < 3; ++k)
+        if (m->fs_stage_bytes[k] < need[k]) {
+            if (m->fs_stage[k]) { HIP_TRY(hipFree(m->fs_stage[k])); m->fs_stage[k] = nullptr; m->fs_stage_bytes[k] = 0; }
+            HIP_TRY(hipMalloc(&m->fs_stage[k], need[k] + need[k] / 4 + 4096));
+            m->fs_stage_bytes[k] = need[k] + need[k] / 4 + 4096;
+        }
+    void *d_rays = m->fs_stage[0], *d_states = m->fs_stage[1], *d_out = m->fs_stage[2];
+    HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(gpis_ray_in), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_states, states, n * sizeof(gpis_fs_state), hipMemcpyHostToDevice));
+    int st = fs_launch(want_sample, m, n, (const gpis_ray_in *)d_rays, (gpis_fs_state *)d_states, want_sample ? (gpis_seg_out *)d_out : nullptr,
+                       want_sample ? nullptr : (uint8_t *)d_out, nullptr);
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(states, d_states, n * sizeof(gpis_fs_state), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out, n * out_rec, hipMemcpyDeviceToHost));
+    return GPIS_OK;
+}
+extern "C" int gpis_fs_sample_distance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && states && out)));
+    return fs_host(m, true, n, rays, states, out);
+}
+extern "C" int gpis_fs_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, uint8_t *visible)
+{
+    CHECK_ARGS(m && (n == 0 || (rays && states && visible)));
+    return fs_host(m, false, n, rays, states, visible);
 }
 extern "C" int gpis_mean_color_emission_host(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3)
 {
@@ -1758,7 +1828,7 @@ extern "C" int gpis_reset_counters(gpis_medium *m)
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(m->d_counters, 0, 2 * sizeof(Counters)));
     HIP_TRY(hipMemset(m->d_guide_cnt, 0, 4 * sizeof(unsigned long long)));
-    for (int k = 0; k < 2; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
+    for (int k = 0; k < 3; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
     return GPIS_OK;
 }
 
@@ -1851,7 +1921,7 @@ extern "C" int gpis_set_profiling(gpis_medium *m, int enable)
 }
 extern "C" int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_t *launches, uint64_t *n_eval, uint64_t *n_seg)
 {
-    CHECK_ARGS(m && (which == 0 || which == 1));
+    CHECK_ARGS(m && which >= 0 && which <= 2);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipDeviceSynchronize());
     for (size_t i = 0; i < m->events_used[which]; ++i) {
@@ -1865,8 +1935,8 @@ extern "C" int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_
     HIP_TRY(hipMemcpy(c, m->d_counters, sizeof c, hipMemcpyDeviceToHost));
     if (total_ms) *total_ms = m->prof_ms[which];
     if (launches) *launches = m->prof_launches[which];
-    if (n_eval) *n_eval = c[which].n_eval;
-    if (n_seg) *n_seg = c[which].n_seg;
+    if (n_eval) *n_eval = which < 2 ? c[which].n_eval : 0;      // the NEE queries count into the sampleDistance pair
+    if (n_seg) *n_seg = which < 2 ? c[which].n_seg : 0;
     return GPIS_OK;
 }
 
@@ -2092,23 +2162,31 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
     hipStream_t st = (hipStream_t)stream;
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = scene_rows(*s) * s->width;
-    size_t chunk_pixels = ((size_t)1 << chunk_log2(m, 24)) / s->spp_count;
-    if (chunk_pixels < 1) chunk_pixels = 1;
-    if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
-    const size_t ns_max = chunk_pixels * s->spp_count;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    // ≈ 800 B per sample (rays, results, the two query records, two shadow rays, masks): the largest chunk the device can hold,
+    // starting from the whole frame (2^27 samples ≈ 106 GB for C2's 1920x1080x64) — every launch ends in a tail of half-empty waves
     PathArrays a;
     NeeArrays b;
-    size_t o_rays = carve(ns_max * sizeof(gpis_ray_in)), o_seg = carve(ns_max * sizeof(gpis_seg_out));
-    size_t o_rng = carve(ns_max * 8), o_thr = carve(ns_max * 4), o_em = carve(ns_max * 4), o_alive = carve(ns_max);
-    size_t o_coeff = carve(ns_max * sizeof(gpis_cond_coeff)), o_qh = carve(ns_max * sizeof(gpis_nee_query)), o_qn = carve(ns_max * sizeof(gpis_nee_query));
-    size_t o_aux = carve(ns_max * sizeof(NeeAux)), o_shl = carve(ns_max * sizeof(gpis_ray_in)), o_shp = carve(ns_max * sizeof(gpis_ray_in));
-    size_t o_ph = carve(ns_max * 4), o_gh = carve(ns_max * 12), o_pn = carve(ns_max * 4), o_cl = carve(ns_max * 4), o_cp = carve(ns_max * 4);
-    size_t o_f[7];
-    for (int k = 0; k < 7; ++k) o_f[k] = carve(ns_max);
-    int rc = ensure_stage(m, 3, off);
-    if (rc) return rc;
+    size_t chunk_pixels = 0, ns_max = 0, off = 0;
+    size_t o_rays = 0, o_seg = 0, o_rng = 0, o_thr = 0, o_em = 0, o_alive = 0, o_coeff = 0, o_qh = 0, o_qn = 0, o_aux = 0, o_shl = 0, o_shp = 0;
+    size_t o_ph = 0, o_gh = 0, o_pn = 0, o_cl = 0, o_cp = 0, o_f[7] = {0};
+    int rc = GPIS_OK;
+    for (int l = chunk_log2(m, 27);; --l) {
+        chunk_pixels = ((size_t)1 << l) / s->spp_count;
+        if (chunk_pixels < 1) chunk_pixels = 1;
+        if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
+        ns_max = chunk_pixels * s->spp_count;
+        off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        o_rays = carve(ns_max * sizeof(gpis_ray_in)); o_seg = carve(ns_max * sizeof(gpis_seg_out));
+        o_rng = carve(ns_max * 8); o_thr = carve(ns_max * 4); o_em = carve(ns_max * 4); o_alive = carve(ns_max);
+        o_coeff = carve(ns_max * sizeof(gpis_cond_coeff)); o_qh = carve(ns_max * sizeof(gpis_nee_query)); o_qn = carve(ns_max * sizeof(gpis_nee_query));
+        o_aux = carve(ns_max * sizeof(NeeAux)); o_shl = carve(ns_max * sizeof(gpis_ray_in)); o_shp = carve(ns_max * sizeof(gpis_ray_in));
+        o_ph = carve(ns_max * 4); o_gh = carve(ns_max * 12); o_pn = carve(ns_max * 4); o_cl = carve(ns_max * 4); o_cp = carve(ns_max * 4);
+        for (int k = 0; k < 7; ++k) o_f[k] = carve(ns_max);
+        if (try_stage(m, 3, off))
+            break;
+        if (l <= 20) return set_err(GPIS_ERR_DEVICE, "NEE driver: no memory for a 1 Mi-sample workspace");
+    }
     if ((rc = ws_acquire(m, 0, st))) return rc;
     char *ws = (char *)m->stage[3];
     a.rays = (gpis_ray_in *)(ws + o_rays); a.seg = (gpis_seg_out *)(ws + o_seg); a.shadow = nullptr;
@@ -2128,10 +2206,13 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
         if ((rc = sample_distance_impl(m, ns, a.rays, a.seg, b.coeff, a.alive, st))) return rc;
         k_nee_setup<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);
         if ((rc = launch_check("k_nee_setup"))) return rc;
-        launch::nee(m->d_model, ns, b.q_half, b.pdf_half, b.grad_half, m->d_counters, b.want_light, st);
-        if ((rc = launch_check("k_nee"))) return rc;
-        launch::nee(m->d_model, ns, b.q_normal, b.pdf_normal, nullptr, m->d_counters, b.want_pdf_normal, st);
-        if ((rc = launch_check("k_nee"))) return rc;
+        {
+            ProfScope prof(m, 2, st);
+            launch::nee(m->d_model, ns, b.q_half, b.pdf_half, b.grad_half, m->d_counters, b.want_light, st);
+            if ((rc = launch_check("k_nee"))) return rc;
+            launch::nee(m->d_model, ns, b.q_normal, b.pdf_normal, nullptr, m->d_counters, b.want_pdf_normal, st);
+            if ((rc = launch_check("k_nee"))) return rc;
+        }
         k_nee_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);
         if ((rc = launch_check("k_nee_shade"))) return rc;
         if ((rc = transmittance_impl(m, ns, b.shadow_light, b.vis_light, b.go_light, st))) return rc;

@@ -13,6 +13,10 @@ void fs_march(bool want_sample, unsigned grid, const DevModel *d_model, size_t n
     if (want_sample) k_fs_march<true><<<grid, 64, 0, s>>>(d_model, n, rays, states, out, visible, (FsGlob *)workspace);
     else k_fs_march<false><<<grid, 64, 0, s>>>(d_model, n, rays, states, out, visible, (FsGlob *)workspace);
 }
+void fs_linalg(unsigned grid, int op, int n, size_t count, const double *in, double *out, double *evals, void *workspace, hipStream_t s)
+{
+    k_fs_linalg<0><<<grid, 64, 0, s>>>(op, n, count, in, out, evals, (FsGlob *)workspace);
+}
 int fs_prof_read(unsigned long long *out16, int reset)
 {
 #ifdef GPIS_FS_PROF

@@ -404,7 +404,7 @@ Vec3f HipSparseConvNoiseMedium::transmittance(PathSampleGenerator &sampler, cons
     uint8_t vis = 0;
     int st = gpis_transmittance_host(_handle, 1, &r, &vis);
     if (st != GPIS_OK) throw std::runtime_error(std::string("gpis_transmittance_host: ") + gpis_last_error());
-    state->firstScatter = false;   // the march ran (GPM.cpp:380); shadow rays work on a copy of the state
+    if (!vis) state->firstScatter = false;   // cleared on a hit only (GPM.cpp:371-381); lastAniso is not returned: shadow rays work on a copy of the state
     Vec3f out;
     out.x = out.y = out.z = vis ? 1.f : 0.f;
     return out;

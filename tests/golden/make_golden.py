@@ -8,6 +8,9 @@ Two kinds of vectors (the reference ships no tests, fixtures or scenes for this 
   ref_primitives.npz   produced by the REAL reference compiled in place (oracle/_ref: its own
                        MathUtil.hpp / UniformSampler.hpp / TangentFrame.hpp / Gaussian.cpp):
                        xxhash32 x4, PCG32 streams, the per-impulse draw order, Duff ONB, Box–Muller.
+  ref_fs_primitives.npz  produced by the REAL reference compiled in place: Eigen's SelfAdjointEigenSolver / LLT, the
+                       MultivariateNormalDistribution of sampling/Gaussian.cpp, pseudo-inverse / conditioning product forms,
+                       rand_truncated_normal, fbm / simplex3d / random3 of math/SdfFunctions.cpp.
   reference_kat.json   the outputs the reference's evaluator printed in this image.
   oracle_*.npz         inputs + outputs of the oracle (CPU restatement) for every mode of the path.
                        They pin the HIP path and guard the oracle against regressions; they are
@@ -78,6 +81,100 @@ def ref_primitives():
     cap_in = rng.uniform(-0.99, 0.9999, 128).astype(f32)
     out.update(cap_pdf_in=cap_in, cap_pdf_out=np.array([ref.ref_uniform_spherical_cap_pdf(float(c)) for c in cap_in], dtype=f32))
     np.savez_compressed(os.path.join(HERE, "ref_primitives.npz"), **out)
+
+
+def _se(x, y=None, l=0.05, s2=0.01):
+    y = x if y is None else y
+    return s2 * np.exp(-(x[:, None] - y[None, :]) ** 2 / (2 * l * l))
+
+
+def ref_fs_primitives():
+    """ref_fs_primitives.npz — the function-space path's linear-algebra / sampling layer and the fbm noise, produced by the REAL
+    reference compiled in place (oracle/_ref): Eigen::SelfAdjointEigenSolver / LLT of the vendored Eigen under the reference's
+    flags, MultivariateNormalDistribution (sampling/Gaussian.cpp:121-232) with sampling/UniformPathSampler.hpp, the Eigen
+    expression forms of pseudo_inverse and create_mvn_cond (GaussianProcess.cpp:645-662, 693, 736-745), rand_truncated_normal,
+    and fbm / simplex3d / random3 (math/SdfFunctions.cpp:199-296).  Matrices are stored as numpy arrays a[i, j]."""
+    ref = ob.ref_lib()
+    assert ref is not None, "oracle/_ref must be built (needs /root/reference)"
+    vp, ci, u64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_double
+    ref.ref_fs_eigh.argtypes = [ci, vp, vp, vp]
+    ref.ref_fs_llt.argtypes = [ci, vp, vp]
+    ref.ref_mvn_norm_transform.argtypes = [ci, vp, vp, vp]
+    ref.ref_fs_pinv_forms.argtypes = [ci, vp, vp]
+    ref.ref_fs_cond_forms.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    ref.ref_mvn_sample.argtypes = [ci, vp, vp, u64, ci, vp, vp, ci, vp, vp]
+    ref.ref_rand_truncated_normal.restype = dbl
+    ref.ref_rand_truncated_normal.argtypes = [dbl, dbl, dbl, u64, vp]
+    ref.ref_fbm.restype = dbl
+    ref.ref_fbm.argtypes = [vp, ci]
+    ref.ref_simplex3d.restype = ctypes.c_float
+    ref.ref_simplex3d.argtypes = [vp]
+    ref.ref_random3.argtypes = [vp, vp]
+    rng = np.random.default_rng(20261005)
+    F = np.asfortranarray
+    out = {}
+    # eigen-solver: a random symmetric matrix and the C4 kind (squared exponential on a fine grid: numerical rank ~20), n = 66 = the
+    # Global context's largest system; a clustered grid (a crossing point between two of its own conditioning points)
+    x66 = np.sort(np.concatenate([np.linspace(0, 0.64, 64), [0.3001, 0.30015]]))
+    cases = {"rand33": (lambda a: a + a.T)(rng.standard_normal((33, 33))), "se64": _se(np.linspace(0, 0.64, 64)), "se66": _se(x66)}
+    for name, a in cases.items():
+        n = a.shape[0]
+        A, V, w = F(a), np.zeros((n, n), order="F"), np.zeros(n)
+        assert ref.ref_fs_eigh(n, P(A), P(V), P(w)) == 0
+        out.update({"eigh_%s_in" % name: a, "eigh_%s_vec" % name: np.array(V), "eigh_%s_val" % name: w})
+    # LLT: well conditioned (success, blocked path with a 2-row tail), barely positive definite, and singular (failure -> eigen square root)
+    a = rng.standard_normal((58, 58))
+    llt_cases = {"spd58": a @ a.T + 58 * np.eye(58), "se40_jitter": _se(np.linspace(0, 2.0, 40)) + 1e-12 * np.eye(40), "se64": cases["se64"]}
+    for name, a in llt_cases.items():
+        n = a.shape[0]
+        S, L_, T = F(a), np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
+        info = ref.ref_fs_llt(n, P(S), P(L_))
+        ref.ref_mvn_norm_transform(n, P(np.zeros(n)), P(S), P(T))
+        out.update({"llt_%s_in" % name: a, "llt_%s_info" % name: np.int32(info), "llt_%s_T" % name: np.array(T)})
+    # pseudo-inverse (66: the last two rows take gebp's split accumulators) and the conditioning products
+    A, o = F(cases["se66"]), np.zeros((66, 66), order="F")
+    ref.ref_fs_pinv_forms(66, P(A), P(o))
+    out["pinv_se66"] = np.array(o)
+    nc, n = 66, 64
+    xc, xs = x66, np.linspace(0.64, 1.28, 64)
+    pin, s12, s22 = F(np.array(o)), F(_se(xc, xs)), F(_se(xs))
+    resid, mu = rng.standard_normal(nc) * 0.05, rng.standard_normal(n) * 0.05
+    m1, c1 = np.zeros(n), np.zeros((n, n), order="F")
+    ref.ref_fs_cond_forms(nc, n, P(pin), P(s12), P(s22), P(resid), P(mu), P(m1), P(c1))
+    out.update(cond_s12=np.array(s12), cond_s22=np.array(s22), cond_resid=resid, cond_mean=mu, cond_mean_out=m1, cond_cov_out=np.array(c1))
+    # MVN samples through the reference's own sampler, with and without constraints; the sampler state afterwards
+    mv_in, mv_out = [], []
+    for k, (name, st) in enumerate((("se64", 0x1234567), ("spd58", 77), ("se40_jitter", 2 ** 40 + 5))):
+        a = cases.get(name, llt_cases.get(name))
+        n = a.shape[0]
+        mu = np.linspace(-0.02, 0.03, n)
+        cidx, cmm = np.array([0, 3, n // 2, n // 2], dtype=np.int32), np.array([-0.3, 0.4, -50.0, 50.0], dtype=np.float32)
+        for ncon in (0, 2):
+            o, so = np.zeros(n), u64()
+            ref.ref_mvn_sample(n, P(mu), P(F(a)), st, ncon, P(cidx), P(cmm), 1, P(o), ctypes.byref(so))
+            out["mvn_%s_c%d" % (name, ncon)] = o
+            out["mvn_%s_c%d_state" % (name, ncon)] = np.uint64(so.value)
+    out.update(mvn_constraint_idx=cidx, mvn_constraint_minmax=cmm)
+    tn_in = np.column_stack([rng.normal(size=64), np.abs(rng.normal(size=64)) + 0.01, rng.normal(size=64) * 2])
+    tn_in[::3, 2] = tn_in[::3, 0]
+    tn_state = rng.integers(1, 2 ** 63, size=64, dtype=np.uint64)
+    tn_out, tn_so = np.zeros(64), np.zeros(64, dtype=np.uint64)
+    for i in range(64):
+        so = u64()
+        tn_out[i] = ref.ref_rand_truncated_normal(tn_in[i, 0], tn_in[i, 1], tn_in[i, 2], int(tn_state[i]), ctypes.byref(so))
+        tn_so[i] = so.value
+    out.update(truncnorm_in=tn_in, truncnorm_state=tn_state, truncnorm_out=tn_out, truncnorm_state_out=tn_so)
+    # fbm noise
+    uv = rng.uniform(-4, 4, (512, 3))
+    out.update(fbm_in=uv, fbm_oct2=np.array([ref.ref_fbm(P(u), 2) for u in uv]), fbm_oct10=np.array([ref.ref_fbm(P(u), 10) for u in uv]))
+    pts = rng.uniform(-30, 30, (512, 3)).astype(f32)
+    out.update(simplex_in=pts, simplex_out=np.array([ref.ref_simplex3d(P(q)) for q in pts], dtype=f32))
+    cs = np.floor(rng.uniform(-60, 60, (512, 3))).astype(f32)
+    r3 = np.zeros((512, 3), dtype=f32)
+    for i in range(512):
+        ref.ref_random3(P(cs[i]), P(r3[i]))
+    out.update(random3_in=cs, random3_out=r3)
+    np.savez_compressed(os.path.join(HERE, "ref_fs_primitives.npz"), **out)
 
 
 def queries(n, seed, spread=1.4):
@@ -160,6 +257,7 @@ def reference_kat():
 if __name__ == "__main__":
     ob.build()
     ref_primitives()
+    ref_fs_primitives()
     reference_kat()
     oracle_vectors()
     print(sorted(os.listdir(HERE)))

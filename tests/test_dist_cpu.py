@@ -1,6 +1,7 @@
 """world_size-2 `gloo` test of the multi-GPU sharding logic on CPU: the same
 `scgt_amd.dist.render_sharded` driver bench.py uses, with the oracle renderer injected (the HIP
-renderer needs a GPU).  Checks: parameter broadcast, both shardings, reduce to rank 0, and that
+renderer needs a GPU).  Checks: parameter broadcast, both shardings, the gather of disjoint tile rows
+("rows") / reduce ("spp") to rank 0, the per-rank timing record, and that
 the sharded image equals the single-process image bit for bit (per-pixel sums of disjoint spp
 slices differ only by fp32 association — compared with a tight tolerance for "spp", exactly for
 "rows")."""
@@ -44,7 +45,10 @@ def _worker(rank, world, port, mode, out_path):
     def render_into(part, acc):
         acc += torch.from_numpy(orc.render_scene_s(part).reshape(-1))
 
-    pkg.dist.render_sharded(scene, render_into, rad, dist=dist, mode=mode)
+    st = pkg.dist.render_sharded(scene, render_into, rad, dist=dist, mode=mode)
+    assert st["render_s"] > 0 and st["collective_s"] >= 0
+    # "rows": only this rank's rows travel (padded to the largest share: 24 of the 40 rows); "spp": the whole frame
+    assert st["wire_bytes"] == (24 * w * 4 if mode == "rows" else h * w * 4)
     if rank == 0:
         np.save(out_path, rad.numpy().reshape(h, w) / pkg.dist.total_spp(scene, world, mode))
     dist.barrier()

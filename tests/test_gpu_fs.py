@@ -138,3 +138,28 @@ def test_function_space_spherical_mean_and_errors(pkg, ob):
         pkg.Medium(bad).fs_sample_distance(rays[:4], st[:4])
     with pytest.raises(RuntimeError):
         ob.Oracle(bad).fs_sample_distance(rays[:4], st[:4])
+
+
+def test_dense_linear_algebra_bit_equal_to_the_reference_eigen(pkg):
+    """The device's eigen-solver, LLT / normTransform and pseudo-inverse (gpis_fs_linalg_batch, one wave per matrix) on the matrices
+    of tests/golden/ref_fs_primitives.npz — produced by the reference's vendored Eigen compiled in place under the reference's flags
+    (tests/golden/make_golden.py: ref_fs_primitives).  Only +, -, *, / and sqrt run in these routines and the device follows Eigen's
+    own reduction orders (packet sums, gebp's split accumulators, the blocked LLT): every output bit equals the reference's."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fs_primitives.npz"))
+    p = pkg.params_for_config("C4")
+    med = pkg.Medium(p)
+    for name in ("rand33", "se64", "se66"):
+        vec, val = med.fs_linalg("eigh", g["eigh_%s_in" % name][None])
+        assert np.array_equal(val[0], g["eigh_%s_val" % name]), name
+        assert np.array_equal(vec[0], g["eigh_%s_vec" % name]), name
+    for name in ("spd58", "se40_jitter", "se64"):
+        t = med.fs_linalg("norm_transform", g["llt_%s_in" % name][None])
+        assert np.array_equal(t[0], g["llt_%s_T" % name]), name
+    pin = med.fs_linalg("pinv", g["eigh_se66_in"][None])
+    assert np.array_equal(pin[0], g["pinv_se66"])
+    # a batch larger than the resident grid, mixed sizes one at a time: the same bits for every copy
+    stack = np.repeat(g["eigh_se64_in"][None], 1500, axis=0)
+    vec, val = med.fs_linalg("eigh", stack)
+    assert (vec == g["eigh_se64_vec"][None]).all() and (val == g["eigh_se64_val"][None]).all()
+

@@ -13,8 +13,8 @@ REF = "/root/reference/src"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
 
 
-def _compile(tmp_path, extra_src=None):
-    src = os.path.join(ROOT, "integration", "HipSparseConvNoiseMedium.cpp")
+def _compile(tmp_path, extra_src=None, unit="HipSparseConvNoiseMedium.cpp"):
+    src = os.path.join(ROOT, "integration", unit)
     if extra_src is not None:
         src = extra_src
     obj = str(tmp_path / "binding.o")
@@ -81,3 +81,48 @@ bool drive(const Medium &m, PathSampleGenerator &sampler, const Ray &ray)
 ''')
     r, _ = _compile(tmp_path, str(tu))
     assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_function_space_binding_compiles_and_is_instantiable(tmp_path):
+    """integration/HipFunctionSpaceMedium.{hpp,cpp}: the Medium subclass for FunctionSpaceGaussianProcessMedium
+    (FunctionSpaceGaussianProcessMedium.cpp:34-43, 58-345) against the real Medium.hpp, PathSampleGenerator.hpp and UniformSampler.hpp
+    (it moves the state of sampler.uniformGenerator() to the device and back)."""
+    r, obj = _compile(tmp_path, unit="HipFunctionSpaceMedium.cpp")
+    assert r.returncode == 0, r.stderr[-4000:]
+    syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True).stdout
+    for needle in (
+        "Tungsten::HipFunctionSpaceMedium::sampleDistance(Tungsten::PathSampleGenerator&, Tungsten::Ray const&, "
+        "Tungsten::Medium::MediumState&, Tungsten::MediumSample&) const",
+        "Tungsten::HipFunctionSpaceMedium::transmittance(Tungsten::PathSampleGenerator&, Tungsten::Ray const&, bool, bool, "
+        "Tungsten::Medium::MediumState*) const",
+        "Tungsten::HipFunctionSpaceMedium::fromJson(Tungsten::JsonPtr, Tungsten::Scene const&)",
+    ):
+        assert needle in syms, needle
+    header = open(os.path.join(ROOT, "include", "gpis.h")).read()
+    undefined = [l.split()[-1] for l in syms.splitlines() if " U gpis_" in l]
+    assert "gpis_fs_sample_distance_host" in undefined and "gpis_fs_transmittance_host" in undefined
+    for u in undefined:
+        assert u + "(" in header, u
+    tu = tmp_path / "use_fs.cpp"
+    tu.write_text(r'''
+#include "HipFunctionSpaceMedium.hpp"
+#include "sampling/UniformPathSampler.hpp"
+#include <memory>
+using namespace Tungsten;
+std::shared_ptr<Medium> make() { return std::make_shared<HipFunctionSpaceMedium>(); }
+bool drive(const Medium &m, const Ray &ray)
+{
+    UniformPathSampler sampler(0xBA5EBA11u);           // its next1D() is the generator whose state the binding hands to the device
+    Medium::MediumState state;
+    state.reset();
+    MediumSample sample;
+    bool ok = m.sampleDistance(sampler, ray, state, sample);
+    Medium::MediumState shadow = state;                 // TraceBase.cpp:79-85: shadow rays run on a copy
+    Vec3f tr = m.transmittance(sampler, ray, false, false, &shadow);
+    GPContextHipFs *ctxt = dynamic_cast<GPContextHipFs *>(state.gpContext.get());
+    return ok && tr.x() >= 0.f && ctxt && ctxt->st.has_context && shadow.gpContext != state.gpContext && sample.gpId == state.lastGPId;
+}
+''')
+    r, _ = _compile(tmp_path, str(tu))
+    assert r.returncode == 0, r.stderr[-4000:]
+
