@@ -1331,6 +1331,8 @@ static int launch_persist(gpis_medium *m, PersistArgs a, hipStream_t s)
     launch::persist_march(inst, WANT_SAMPLE, grid, m->d_model, a, s);
     return launch_check("k_persist_march");
 }
+// neePDF / neeGrad: the 1D-sampling instance for the media the NEE estimators are built for, else the all-features one
+static int nee_instance(const DevModel &H) { return (H.sampling_1d && !H.fbm_noise) ? launch::INST_1D : launch::INST_GENERIC; }
 // the lane-per-ray instance whose compile-time flags equal the medium's
 static int lane_instance(const DevModel &H)
 {
@@ -1476,7 +1478,7 @@ extern "C" int gpis_nee_pdf_batch(gpis_medium *m, size_t n, const gpis_nee_query
     CHECK_ARGS(m && (n == 0 || (q && pdf)));
     if (n == 0) return GPIS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    launch::nee(m->d_model, n, q, pdf, nullptr, m->d_counters, nullptr, (hipStream_t)stream);
+    launch::nee(nee_instance(m->host_model), m->d_model, n, q, pdf, nullptr, m->d_counters, nullptr, (hipStream_t)stream);
     return launch_check("k_nee");
 }
 extern "C" int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_query *q, float *grad3, void *stream)
@@ -1484,7 +1486,7 @@ extern "C" int gpis_nee_grad_batch(gpis_medium *m, size_t n, const gpis_nee_quer
     CHECK_ARGS(m && (n == 0 || (q && grad3)));
     if (n == 0) return GPIS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    launch::nee(m->d_model, n, q, nullptr, grad3, m->d_counters, nullptr, (hipStream_t)stream);
+    launch::nee(nee_instance(m->host_model), m->d_model, n, q, nullptr, grad3, m->d_counters, nullptr, (hipStream_t)stream);
     return launch_check("k_nee");
 }
 extern "C" int gpis_mean_color_emission_batch(gpis_medium *m, size_t n, const double *p3, float *color3, float *emission3, void *stream)
@@ -2208,9 +2210,9 @@ extern "C" int gpis_render_scene_s_nee(gpis_medium *m, const gpis_scene_s *s, co
         if ((rc = launch_check("k_nee_setup"))) return rc;
         {
             ProfScope prof(m, 2, st);
-            launch::nee(m->d_model, ns, b.q_half, b.pdf_half, b.grad_half, m->d_counters, b.want_light, st);
+            launch::nee(nee_instance(m->host_model), m->d_model, ns, b.q_half, b.pdf_half, b.grad_half, m->d_counters, b.want_light, st);
             if ((rc = launch_check("k_nee"))) return rc;
-            launch::nee(m->d_model, ns, b.q_normal, b.pdf_normal, nullptr, m->d_counters, b.want_pdf_normal, st);
+            launch::nee(nee_instance(m->host_model), m->d_model, ns, b.q_normal, b.pdf_normal, nullptr, m->d_counters, b.want_pdf_normal, st);
             if ((rc = launch_check("k_nee"))) return rc;
         }
         k_nee_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, *surf, ns, a, b);

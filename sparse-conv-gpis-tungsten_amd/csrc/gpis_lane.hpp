@@ -141,7 +141,10 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(kBlock) k_conditioning(const De
     }
     flush_counters(cnt, r.n_eval, 0);
 }
-GPIS_TU_KERNEL __global__ void __launch_bounds__(kBlock) k_nee(const DevModel *__restrict__ Mp, size_t n, const gpis_nee_query *__restrict__ q,
+// neePDF / neeGrad queries (the BSDF hooks and the NEE driver).  P = the path instance: the NEE driver's medium is the 1D-sampling
+// one (config C2), which gets the specialised instance; everything else the all-features one.
+template <class P>
+__global__ void __launch_bounds__(kBlock) k_nee(const DevModel *__restrict__ Mp, size_t n, const gpis_nee_query *__restrict__ q,
                                                 float *__restrict__ pdf, float *__restrict__ grad3, Counters *cnt,
                                                 const uint8_t *__restrict__ mask = nullptr)
 {
@@ -151,9 +154,9 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(kBlock) k_nee(const DevModel *_
         gpis_nee_query qq = q[i];
         r.c = qq.coeff;
         V3 rd = v3(qq.ray_dir[0], qq.ray_dir[1], qq.ray_dir[2]), nn = v3(qq.normal[0], qq.normal[1], qq.normal[2]), p = v3(qq.p[0], qq.p[1], qq.p[2]);
-        if (pdf) pdf[i] = generic::nee_pdf(*Mp, r, rd, nn, p, qq.t_segment, info_of(qq));
+        if (pdf) pdf[i] = P::nee_pdf_of(*Mp, r, rd, nn, p, qq.t_segment, info_of(qq));
         if (grad3) {
-            V3 g = generic::nee_grad(*Mp, r, rd, nn, p, info_of(qq));
+            V3 g = P::nee_grad_of(*Mp, r, rd, nn, p, info_of(qq));
             grad3[3 * i] = g.x; grad3[3 * i + 1] = g.y; grad3[3 * i + 2] = g.z;
         }
     }

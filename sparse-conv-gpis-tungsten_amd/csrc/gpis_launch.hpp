@@ -38,7 +38,7 @@ void persist_march(int inst, bool want_sample, unsigned grid, const DevModel *d_
 void eval_value(const DevModel *d_model, size_t n, const gpis_query *q, float *value, int32_t *gp_id, Counters *cnt, hipStream_t s);
 void eval_gradient(const DevModel *d_model, size_t n, const gpis_query *q, float *grad3, Counters *cnt, hipStream_t s);
 void conditioning(const DevModel *d_model, size_t n, const gpis_query *q, const float *tv, const float *tg, gpis_cond_coeff *co, Counters *cnt, hipStream_t s);
-void nee(const DevModel *d_model, size_t n, const gpis_nee_query *q, float *pdf, float *grad3, Counters *cnt, const uint8_t *mask, hipStream_t s);
+void nee(int inst, const DevModel *d_model, size_t n, const gpis_nee_query *q, float *pdf, float *grad3, Counters *cnt, const uint8_t *mask, hipStream_t s);   // inst: INST_1D or INST_GENERIC
 // ---- wave-cooperative march for single-realization media (tu_fast.hip) ---------------------------------------
 int fast_table_build(const DevModel &M, FastTable *t);
 void fast_sample_distance(const DevModel *d_model, const FastTable &T, size_t n, const gpis_ray_in *rays, gpis_seg_out *out, gpis_cond_coeff *coeff,

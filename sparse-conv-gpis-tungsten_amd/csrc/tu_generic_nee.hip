@@ -8,9 +8,10 @@
 
 namespace gpis { namespace launch {
 
-void nee(const DevModel *d_model, size_t n, const gpis_nee_query *q, float *pdf, float *grad3, Counters *cnt, const uint8_t *mask, hipStream_t s)
+void nee(int inst, const DevModel *d_model, size_t n, const gpis_nee_query *q, float *pdf, float *grad3, Counters *cnt, const uint8_t *mask, hipStream_t s)
 {
-    k_nee<0><<<grid_of(n, kBlock), kBlock, 0, s>>>(d_model, n, q, pdf, grad3, cnt, mask);
+    if (inst == INST_1D) k_nee<spec_1d::Path><<<grid_of(n, kBlock), kBlock, 0, s>>>(d_model, n, q, pdf, grad3, cnt, mask);
+    else k_nee<generic::Path><<<grid_of(n, kBlock), kBlock, 0, s>>>(d_model, n, q, pdf, grad3, cnt, mask);
 }
 
 }}   // namespace gpis::launch
