@@ -232,8 +232,8 @@ def main():
                          "slice of every pixel (weak scaling, N times the samples)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / sharding self-test over gloo on CPU: no GPU work, no metric")
     ap.add_argument("--guide", default="16:64", help="certified guide field 'half_extent_cells:points_per_cell' for "
-                    "single-realization media, or 'off' (built once before the timed region: 34 GB / 2 s at 16:64, "
-                    "4.3 GB / 0.3 s at 16:32; falls back to 16:32 if the allocation fails)")
+                    "single-realization media, or 'off' (built once before the timed region; only the bricks near the surface are "
+                    "tabulated: a few GB at 16:64 for scene S; falls back to 16:32 if the allocation fails)")
     ap.add_argument("--estimator", choices=["auto", "lambert", "nee"], default="auto",
                     help="auto: C2 (1D sampling, MIS, conductor) renders through the conductor NEE estimator (gpis_render_scene_s_nee, "
                          "TraceBase.cpp:346-420 / ConductorBsdf.cpp:68-137) as BASELINE.json states it, everything else through scene S's "
@@ -294,7 +294,9 @@ def main():
         except RuntimeError:
             half, ppc = 16, 32
             med.build_guide(half, ppc)
-        guide_info = {"half_extent_cells": half, "points_per_cell": ppc, "bytes": (2 * half * ppc) ** 3 * 4,
+        gi = med.guide_info()
+        guide_info = {"half_extent_cells": half, "points_per_cell": ppc, "bytes": gi["bytes_samples"] + gi["bytes_bounds"],
+                      "bytes_dense_equivalent": gi["bytes_dense"], "bricks_tabulated": gi["bricks_allocated"], "bricks_total": gi["bricks_total"],
                       "build_s": time.perf_counter() - t_g}
 
     use_nee = args.estimator == "nee" or (args.estimator == "auto" and args.config == "C2")

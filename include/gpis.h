@@ -470,6 +470,16 @@ int gpis_get_kernel_profile(gpis_medium *m, int which, double *total_ms, uint64_
  * the wave-cooperative path does not cover.  gpis_drop_guide frees it. */
 int gpis_build_guide(gpis_medium *m, int half_extent_cells, int points_per_cell);
 int gpis_drop_guide(gpis_medium *m);
+/* Size of the guide field: the samples are stored in bricks of 16^3 grid points and only the bricks in which the certificate can be
+ * asked for more than the mean (|mean| within sigma * bound(|N|) / norm somewhere in the brick) are tabulated; everywhere else
+ * every step is decided by the mean alone.  bytes_dense = what the full grid would take.  All zero without a guide field. */
+typedef struct gpis_guide_info {
+    int32_t half_extent_cells, points_per_cell;
+    uint64_t bricks_total, bricks_allocated, bricks_usable;
+    uint64_t bytes_samples, bytes_bounds, bytes_dense;
+    uint64_t selfcheck_points_tabulated;      /* of the last gpis_guide_selfcheck: points that fell into tabulated bricks */
+} gpis_guide_info;
+int gpis_get_guide_info(gpis_medium *m, gpis_guide_info *out);
 /* March steps certified by the guide since the last gpis_reset_counters: each stands for one
  * evaluateValue call of the reference (exact evaluations stay in n_eval). */
 int gpis_get_guide_steps(gpis_medium *m, uint64_t *n_guide);

@@ -122,6 +122,11 @@ def default_scene_s(width, height, spp):
     return s
 
 
+GUIDE_INFO = np.dtype([("half_extent_cells", np.int32), ("points_per_cell", np.int32), ("bricks_total", np.uint64), ("bricks_allocated", np.uint64),
+                       ("bricks_usable", np.uint64), ("bytes_samples", np.uint64), ("bytes_bounds", np.uint64), ("bytes_dense", np.uint64),
+                       ("selfcheck_points_tabulated", np.uint64)], align=True)
+
+
 def default_surface_s():
     """Copper-like single-channel conductor and a 12-degree cap light."""
     s = np.zeros((), dtype=SURFACE_S)
@@ -135,7 +140,7 @@ _EXPECTED_SIZES = {
     "gpis_seg_out": SEG_OUT.itemsize, "gpis_cond_coeff": COND_COEFF.itemsize, "gpis_query": QUERY.itemsize,
     "gpis_nee_query": NEE_QUERY.itemsize, "gpis_derived": DERIVED.itemsize, "gpis_scene_s": SCENE_S.itemsize,
     "gpis_surface_s": SURFACE_S.itemsize, "gpis_ramp": RAMP.itemsize,
-    "gpis_fs_state": FS_STATE.itemsize,
+    "gpis_fs_state": FS_STATE.itemsize, "gpis_guide_info": GUIDE_INFO.itemsize,
 }
 assert RAY_IN.itemsize == 128 and SEG_OUT.itemsize == 96 and COND_COEFF.itemsize == 32
 assert QUERY.itemsize == 96 and NEE_QUERY.itemsize == 96
@@ -272,7 +277,7 @@ class GpisLib:
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
-        "gpis_set_batch_order", "gpis_set_option", "gpis_get_option", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
+        "gpis_set_batch_order", "gpis_set_option", "gpis_get_option", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_info", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
         "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
     ]
 
@@ -332,6 +337,7 @@ class GpisLib:
         L.gpis_set_option.argtypes = [vp, i32, ctypes.c_longlong]
         L.gpis_get_option.argtypes = [vp, i32, vp]
         L.gpis_build_guide.argtypes = [vp, i32, i32]
+        L.gpis_get_guide_info.argtypes = [vp, vp]
         L.gpis_drop_guide.argtypes = [vp]
         L.gpis_get_guide_steps.argtypes = [vp, vp]
         L.gpis_guide_selfcheck.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
@@ -510,6 +516,12 @@ class Medium:
 
     def build_guide(self, half_extent_cells=16, points_per_cell=32):
         self.L.check(self.L.lib.gpis_build_guide(self.h, int(half_extent_cells), int(points_per_cell)), "gpis_build_guide")
+
+    def guide_info(self):
+        """dict of the guide field's brick counts and bytes (zeros without a guide field)"""
+        info = np.zeros((), dtype=GUIDE_INFO)
+        self.L.check(self.L.lib.gpis_get_guide_info(self.h, info.ctypes.data_as(ctypes.c_void_p)), "gpis_get_guide_info")
+        return {k: int(info[k]) for k in GUIDE_INFO.names}
 
     def drop_guide(self):
         self.L.check(self.L.lib.gpis_drop_guide(self.h), "gpis_drop_guide")

@@ -39,15 +39,26 @@
 
 namespace gpis {
 
+// Storage: the samples live in BRICKS of 16^3 grid points (+ one layer shared with the +neighbours: 17^3 floats, so the eight taps of
+// a lookup never leave their brick), and only the bricks a march can need at level 1 are tabulated: a brick is needed when, over the
+// world points that can map into it, |mean| can come below sigma * amax / norm, amax = an a-priori bound on |N| over the brick
+// from a field 4x coarser (1/64 of the work).  Everywhere else level 0 (guide_sign_at) decides every step by the mean alone, and
+// the block records say so: Err = +inf there, so level 1 can certify nothing and the exact evaluation takes over — the need
+// analysis decides speed, never results.  Scene S: 8 % of the bricks (2.8 of 34 GB at 16:64).
+constexpr int kBrick = 16;                         // grid points per brick edge = 4 blocks
+constexpr uint32_t kBrickRow = 17, kBrickFloats = 17u * 17u * 17u;
+constexpr uint32_t kNoBrick = 0xFFFFFFFFu;
 struct GuideField {
-    float *G;            // side^3 samples, z fastest
-    float *err;          // (side/4)^3 blocks x 2: the bound Err of the block, and amax = a bound on |N| anywhere in the block's cells
+    float *G;            // pool of tabulated bricks: slot * 17^3 + (lx * 17 + ly) * 17 + lz
+    float *err;          // (side/4)^3 blocks x 2, dense: the bound Err of the block (+inf where the brick is not tabulated), and amax = a bound on |N| anywhere in the block's cells
+    uint32_t *brick;     // (side/16)^3 bricks: slot of the brick's samples in the pool (slot 0 where not tabulated: Err = +inf makes its taps irrelevant)
     int half;            // extent in cells: u in [-half, half)
     int ppc;             // grid points per cell (h = 1/ppc)
     int side;            // 2*half*ppc
     float alpha[3];      // A_a * R^2
     float R;             // kernelRadius of the grid space
     int enabled;
+    uint32_t n_alloc, n_usable;   // bricks in the pool / bricks level 1 may use
 };
 
 #ifndef GPIS_GUIDE_OCC
@@ -89,14 +100,21 @@ constexpr float kGuideCullRadius = 1.0001f;   // beyond this distance from the b
 // r_i(c) - m >= r_i(cB) - mB).  Only the impulses whose cut-off sphere passes near the block take the per-cell
 // classification of the header comment.  (Before: every pair took it, 100 instructions with a correctly rounded sqrtf and four
 // v_readlane; 2.5 s for the 34 GB field.)
-GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t block_offset)
+// Work item = one 4x4x4 block of one ALLOCATED brick (64 per brick): `list[slot]` = the brick, `slot_of[brick]` = its slot or kNoBrick,
+// `need[brick]` = level 1 may use it (then the block's Err is recorded; otherwise the block keeps the a-priori record of k_guide_need).
+GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_guide_build(const DevModel *__restrict__ Mp, FastTable T, GuideField F, size_t item_offset,
+                                                                  const uint32_t *__restrict__ list, const uint32_t *__restrict__ slot_of,
+                                                                  const uint8_t *__restrict__ need)
 {
     __shared__ float4 stage[64];
     const DevModel &M = *Mp;
     const int lane = (int)(threadIdx.x & 63);
-    const int bs = F.side / 4;
-    const size_t b = block_offset + blockIdx.x;
-    const int bz = (int)(b % bs), by = (int)((b / bs) % bs), bx = (int)(b / ((size_t)bs * bs));
+    const int bs = F.side / 4, nbk = F.side / kBrick;
+    const size_t item = item_offset + blockIdx.x;
+    const uint32_t slot = (uint32_t)(item >> 6), sub = (uint32_t)(item & 63);
+    const uint32_t brick = list[slot];
+    const int kz = (int)(brick % nbk), ky = (int)((brick / nbk) % nbk), kx = (int)(brick / ((uint32_t)nbk * nbk));
+    const int bx = 4 * kx + (int)(sub >> 4), by = 4 * ky + (int)((sub >> 2) & 3), bz = 4 * kz + (int)(sub & 3);
     const int lz = lane & 3, ly = (lane >> 2) & 3, lx = lane >> 4;
     const int ix = 4 * bx + lx, iy = 4 * by + ly, iz = 4 * bz + lz;
     const float h = 1.0f / (float)F.ppc;
@@ -206,10 +224,21 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_guide_build(const DevMode
     }
     float err = (h * h * 0.125f) * (Esum + EB) + Tsum + kGuidePosEps * (Lsum + LB);
     err = err * 1.001f + 5e-4f;
-    F.G[((size_t)ix * F.side + (size_t)iy) * F.side + (size_t)iz] = Ssum;
+    // the sample goes to its own brick and, when it lies on a low face of the brick, into the shared layer (local index 16) of the
+    // allocated bricks before it
+    const uint32_t qx = (uint32_t)ix & 15u, qy = (uint32_t)iy & 15u, qz = (uint32_t)iz & 15u;
+    F.G[(size_t)slot * kBrickFloats + (qx * kBrickRow + qy) * kBrickRow + qz] = Ssum;
+    for (int m = 1; m < 8; ++m) {
+        const int ox = m & 1, oy = (m >> 1) & 1, oz = m >> 2;
+        if ((ox && (qx || !kx)) || (oy && (qy || !ky)) || (oz && (qz || !kz)))
+            continue;
+        const uint32_t nslot = slot_of[((uint32_t)(kx - ox) * nbk + (uint32_t)(ky - oy)) * nbk + (uint32_t)(kz - oz)];
+        if (nslot != kNoBrick)
+            F.G[(size_t)nslot * kBrickFloats + ((ox ? 16u : qx) * kBrickRow + (oy ? 16u : qy)) * kBrickRow + (oz ? 16u : qz)] = Ssum;
+    }
     float emax = err;
     for (int off = 32; off > 0; off >>= 1) emax = fmaxf(emax, __shfl_xor(emax, off, 64));
-    if (lane == 0)
+    if (lane == 0 && need[brick])
         F.err[2 * (((size_t)bx * bs + (size_t)by) * bs + (size_t)bz)] = emax;
 }
 
@@ -217,39 +246,172 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_guide_build(const DevMode
 // layer belongs to the neighbouring blocks) + Err(block).  The interpolant of a cell is a convex combination of its corners, so
 // |N_ref(u)| <= |G(u)| + Err <= amax for every u the march can look up in the block: when the mean alone exceeds sigma amax / norm
 // the sign of the field is the sign of the mean, and the march skips the 8-tap lookup (guide_sign_at, level 0).
-GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_amax(GuideField F, size_t block_offset, size_t nblk)
+GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_amax(GuideField F, size_t item_offset, size_t n_items, const uint32_t *__restrict__ list,
+                                                                  const uint8_t *__restrict__ need)
 {
-    const size_t b = block_offset + (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (b >= nblk)
+    const size_t item = item_offset + (size_t)blockIdx.x * 256 + threadIdx.x;     // one 4^3 block of one allocated brick
+    if (item >= n_items)
         return;
-    const int bs = F.side / 4;
-    const int bz = (int)(b % bs), by = (int)((b / bs) % bs), bx = (int)(b / ((size_t)bs * bs));
-    const int last = F.side - 1;
+    const uint32_t slot = (uint32_t)(item >> 6), sub = (uint32_t)(item & 63);
+    const uint32_t brick = list[slot];
+    if (!need[brick])
+        return;                                     // allocated only to complete its neighbours' shared layer: keeps its a-priori record
+    const int bs = F.side / 4, nbk = F.side / kBrick;
+    const int kz = (int)(brick % nbk), ky = (int)((brick / nbk) % nbk), kx = (int)(brick / ((uint32_t)nbk * nbk));
+    const uint32_t sx = sub >> 4, sy = (sub >> 2) & 3, sz = sub & 3;
+    const int bx = 4 * kx + (int)sx, by = 4 * ky + (int)sy, bz = 4 * kz + (int)sz;
+    // the last layer of points of the field's last bricks does not exist (lookups stop at side - 2): clamp like the dense field did
+    const uint32_t lx = kx == nbk - 1 ? 15u : 16u, ly = ky == nbk - 1 ? 15u : 16u, lz = kz == nbk - 1 ? 15u : 16u;
+    const float *Gb = F.G + (size_t)slot * kBrickFloats;
     float m = 0.f;
-    for (int dx = 0; dx <= 4; ++dx) {
-        const int ix = min(4 * bx + dx, last);
-        for (int dy = 0; dy <= 4; ++dy) {
-            const int iy = min(4 * by + dy, last);
-            const float *row = F.G + ((size_t)ix * F.side + (size_t)iy) * F.side;
-            for (int dz = 0; dz <= 4; ++dz)
-                m = fmaxf(m, fabsf(row[min(4 * bz + dz, last)]));
+    for (uint32_t dx = 0; dx <= 4; ++dx) {
+        const uint32_t px = min(4 * sx + dx, lx);
+        for (uint32_t dy = 0; dy <= 4; ++dy) {
+            const float *row = Gb + (px * kBrickRow + min(4 * sy + dy, ly)) * kBrickRow;
+            for (uint32_t dz = 0; dz <= 4; ++dz)
+                m = fmaxf(m, fabsf(row[min(4 * sz + dz, lz)]));
         }
     }
+    const size_t b = ((size_t)bx * bs + (size_t)by) * bs + (size_t)bz;
     F.err[2 * b + 1] = m + F.err[2 * b];
+}
+
+// Which bricks can level 1 be asked about?  One thread per brick: the block records of the brick get the a-priori pair (Err = +inf,
+// amax = the coarse field's bound on |N| over the brick: its block of the same index covers exactly this brick's cells), and the brick
+// is NEEDED when |mean| can come below sigma amax / norm somewhere in it.  The mean is a function of the world point; a brick is a box
+// of the grid space: in world-space sampling a box of world points (p = R u), in isotropic-ray space — where every ray sees the lattice
+// through its own rotation — the shell of world points with |W p| = R |u|, W = diag (no anisoMtx on this path).  Interval bounds per
+// mean type; the CSG minimum of two means takes the minimum of the bounds.  `coarse` == nullptr: every brick is needed (small fields).
+GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_need(const DevModel *__restrict__ Mp, GuideField F, const float *__restrict__ coarse_err, uint8_t *__restrict__ need)
+{
+    const uint32_t nbk = (uint32_t)F.side / kBrick, brick = blockIdx.x * 256u + threadIdx.x;
+    if (brick >= nbk * nbk * nbk)
+        return;
+    const DevModel &M = *Mp;
+    const uint32_t kz = brick % nbk, ky = (brick / nbk) % nbk, kx = brick / (nbk * nbk);
+    const uint32_t bs = (uint32_t)F.side / 4;
+    bool needed = true;
+    float amax = __builtin_huge_valf();
+    if (coarse_err) {
+        amax = coarse_err[2 * (size_t)brick + 1];
+        const float h = 1.0f / (float)F.ppc, pad = 2e-3f;
+        float lo[3], hi[3];                                       // the brick's cells in grid units, padded
+        const uint32_t kk[3] = {kx, ky, kz};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = (float)(kBrick * kk[a]) * h - (float)F.half - pad;
+            hi[a] = lo[a] + (float)kBrick * h + 2.f * pad;
+        }
+        float mlo = __builtin_huge_valf(), mhi = __builtin_huge_valf();      // range of min(mean, mean_additional)
+        for (int w = 0; w < (M.has_mean_additional ? 2 : 1); ++w) {
+            const gpis_mean &mu = M.mean[w];
+            float vlo, vhi;
+            if (mu.type == GPIS_MEAN_HOMOGENEOUS) {
+                vlo = vhi = mu.offset;
+            } else if (!M.iso3d) {
+                // world space: p = R u, a box
+                float dlo = 0.f, dhi = 0.f;
+                if (mu.type == GPIS_MEAN_SPHERICAL) {
+                    float n2 = 0.f, f2 = 0.f;
+                    for (int a = 0; a < 3; ++a) {
+                        const float c = (float)mu.center[a], pl = F.R * lo[a], ph = F.R * hi[a];
+                        const float nearest = fmaxf(fmaxf(pl - c, c - ph), 0.f), farthest = fmaxf(fabsf(pl - c), fabsf(ph - c));
+                        n2 += nearest * nearest; f2 += farthest * farthest;
+                    }
+                    dlo = sqrtf(n2) * 0.9999f; dhi = sqrtf(f2) * 1.0001f;
+                    vlo = dlo - mu.radius; vhi = dhi - mu.radius;
+                } else {
+                    for (int a = 0; a < 3; ++a) {
+                        const float c = (float)mu.center[a], l = (float)M.lin_dir[w][a], x0 = (F.R * lo[a] - c) * l, x1 = (F.R * hi[a] - c) * l;
+                        dlo += fminf(x0, x1); dhi += fmaxf(x0, x1);
+                    }
+                    const float s0 = dlo * mu.scale, s1 = dhi * mu.scale;
+                    vlo = fmaxf(fminf(s0, s1), mu.min); vhi = fmaxf(fmaxf(s0, s1), mu.min);
+                }
+            } else {
+                // isotropic-ray space: |W p| = R |u| for some rotation of u: a shell of |p|
+                float n2 = 0.f, f2 = 0.f, smin = __builtin_huge_valf(), smax = 0.f;
+                for (int a = 0; a < 3; ++a) {
+                    const float nearest = fmaxf(fmaxf(lo[a], -hi[a]), 0.f), farthest = fmaxf(fabsf(lo[a]), fabsf(hi[a]));
+                    n2 += nearest * nearest; f2 += farthest * farthest;
+                    const float sv = fabsf(GM(M.w2l, a, a));
+                    smin = fminf(smin, sv); smax = fmaxf(smax, sv);
+                }
+                const float pmin = F.R * sqrtf(n2) / smax * 0.9999f, pmax = F.R * sqrtf(f2) / smin * 1.0001f;
+                float cn = 0.f;
+                for (int a = 0; a < 3; ++a) cn += (float)mu.center[a] * (float)mu.center[a];
+                cn = sqrtf(cn) * 1.0001f;
+                if (mu.type == GPIS_MEAN_SPHERICAL) {
+                    vlo = fmaxf(fmaxf(pmin - cn, cn - pmax), 0.f) - mu.radius; vhi = pmax + cn - mu.radius;
+                } else {
+                    const float d = (pmax + cn) * 1.0001f, s = fabsf(mu.scale) * d;     // |direction| = 1
+                    vlo = fmaxf(-s, mu.min); vhi = fmaxf(s, mu.min);
+                }
+            }
+            mlo = fminf(mlo, vlo); mhi = fminf(mhi, vhi);
+        }
+        const float abs_lo = (mlo <= 0.f && mhi >= 0.f) ? 0.f : fminf(fabsf(mlo), fabsf(mhi));
+        const float sn = M.sigma / (M.iso3d ? M.norm3d_iso : M.norm3d_world);
+        needed = !(abs_lo > amax * sn * 1.001f + 1e-4f + 1e-5f * fmaxf(fabsf(mlo), fabsf(mhi)));
+    }
+    need[brick] = needed ? 1 : 0;
+    // default records of the brick's 64 blocks: level 1 certifies nothing (Err = +inf), level 0 uses the a-priori bound
+    for (uint32_t s = 0; s < 64; ++s) {
+        const size_t b = ((size_t)(4 * kx + (s >> 4)) * bs + (size_t)(4 * ky + ((s >> 2) & 3))) * bs + (size_t)(4 * kz + (s & 3));
+        F.err[2 * b] = __builtin_huge_valf();
+        F.err[2 * b + 1] = amax;
+    }
+}
+// Allocation: a brick gets samples when it is needed or completes the shared layer of a needed brick before it (one of the seven
+// bricks at -1 along a subset of the axes is needed).  slot_of / list are the two directions of the mapping.
+GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_slots(GuideField F, const uint8_t *__restrict__ need, uint32_t *__restrict__ slot_of,
+                                                                   uint32_t *__restrict__ list, uint32_t *__restrict__ counters)
+{
+    const uint32_t nbk = (uint32_t)F.side / kBrick, brick = blockIdx.x * 256u + threadIdx.x;
+    if (brick >= nbk * nbk * nbk)
+        return;
+    const uint32_t kz = brick % nbk, ky = (brick / nbk) % nbk, kx = brick / (nbk * nbk);
+    bool alloc = false;
+    for (int m = 0; m < 8 && !alloc; ++m) {
+        const uint32_t ox = m & 1, oy = (m >> 1) & 1, oz = m >> 2;
+        if ((ox && !kx) || (oy && !ky) || (oz && !kz))
+            continue;
+        alloc = need[((kx - ox) * nbk + (ky - oy)) * nbk + (kz - oz)] != 0;
+    }
+    uint32_t slot = kNoBrick;
+    if (alloc) {
+        slot = atomicAdd(&counters[0], 1u);
+        list[slot] = brick;
+        if (need[brick]) atomicAdd(&counters[1], 1u);
+    }
+    slot_of[brick] = slot;
+}
+// the lookup table of the finished field: the slot for the bricks level 1 may use, slot 0 for the rest (their Err is +inf)
+GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_table(GuideField F, const uint8_t *__restrict__ need, const uint32_t *__restrict__ slot_of)
+{
+    const uint32_t nbk = (uint32_t)F.side / kBrick, brick = blockIdx.x * 256u + threadIdx.x;
+    if (brick >= nbk * nbk * nbk)
+        return;
+    F.brick[brick] = need[brick] ? slot_of[brick] : 0u;
 }
 
 // G and the bound at index-space coordinates (tx, ty, tz) = (u + half) * ppc; false outside the
 // tabulated volume
-GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err);
+GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err, float &amax);
 
-// G(u) and the bound for the cell containing u; false when u is outside the tabulated volume
-GPIS_DEV bool guide_lookup(const GuideField &F, V3 u, float &g, float &err)
+// G(u), the bound Err for the cell containing u (+inf where the brick is not tabulated) and the block's bound amax on |N|; false when u
+// is outside the field's volume
+GPIS_DEV bool guide_lookup(const GuideField &F, V3 u, float &g, float &err, float &amax)
 {
     const float s = (float)F.ppc, off = (float)F.half;
-    return guide_lookup_index(F, (u.x + off) * s, (u.y + off) * s, (u.z + off) * s, g, err);
+    return guide_lookup_index(F, (u.x + off) * s, (u.y + off) * s, (u.z + off) * s, g, err, amax);
+}
+GPIS_DEV bool guide_lookup(const GuideField &F, V3 u, float &g, float &err)
+{
+    float amax;
+    return guide_lookup(F, u, g, err, amax);
 }
 
-GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err)
+GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err, float &amax)
 {
     typedef const float __attribute__((address_space(1))) *gfloat_p;   // the field is read through a struct in memory: keep the loads global_load
     const float fx0 = floorf(tx), fy0 = floorf(ty), fz0 = floorf(tz);
@@ -262,9 +424,11 @@ GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float 
     const float wx = tx - fx0, wy = ty - fy0, wz = tz - fz0;
     // side <= 8192 (guide_build): ix*side + iy < 2^26 is a 24-bit multiply-add, the element index one 32x32->64 multiply-add
     // (as size_t arithmetic on ints this was 30 instructions of sign extensions and 64x64 multiplies per march step)
-    const uint32_t row = __umul24(ix, side) + iy;
-    gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)row * side + iz);
-    gfloat_p p01 = p00 + side, p10 = p00 + (size_t)side * side, p11 = p10 + side;
+    // the brick's slot (side <= 8192: nbk <= 512, the brick index is a 24-bit multiply-add), then the eight taps inside the brick
+    const uint32_t nbk = side >> 4;
+    const uint32_t slot = ((const uint32_t __attribute__((address_space(1))) *)F.brick)[__umul24(__umul24(ix >> 4, nbk) + (iy >> 4), nbk) + (iz >> 4)];
+    gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)slot * kBrickFloats + (((ix & 15u) * kBrickRow + (iy & 15u)) * kBrickRow + (iz & 15u)));
+    gfloat_p p01 = p00 + kBrickRow, p10 = p00 + kBrickRow * kBrickRow, p11 = p10 + kBrickRow;
     const float a000 = p00[0], a001 = p00[1], a010 = p01[0], a011 = p01[1];
     const float a100 = p10[0], a101 = p10[1], a110 = p11[0], a111 = p11[1];
     // fused lerps: the guide value is not part of any result, its rounding is inside the stored bound's 5e-4 + 1e-3 relative
@@ -274,7 +438,9 @@ GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float 
     g = __builtin_fmaf(c1 - c0, wx, c0);
     const uint32_t bs = side >> 2;
     const uint32_t brow = __umul24(ix >> 2, bs) + (iy >> 2);
-    err = ((gfloat_p)F.err)[2u * ((uint64_t)brow * bs + (iz >> 2))];
+    gfloat_p pe = (gfloat_p)F.err + 2u * ((uint64_t)brow * bs + (iz >> 2));
+    err = pe[0];                      // +inf where the brick is not tabulated (g is then some other brick's value: never used against a finite bound)
+    amax = pe[1];
     return true;
 }
 
@@ -434,10 +600,15 @@ GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRa
     if (fabsf(mean) > e_amax * gr.sn * 1.0001f + ms + 4e-6f * fabsf(mean) + 1e-7f)
         return mean > 0.f ? 1 : -1;
     // level 1
+    if (!(e_err < 3e38f))
+        return 0;                    // the brick is not tabulated: nothing to certify with (the exact evaluation decides)
     const float wx = tx - fx0, wy = ty - fy0, wz = tz - fz0;
-    const uint32_t row = __umul24(ix, side) + iy;
-    gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)row * side + iz);
-    gfloat_p p01 = p00 + side, p10 = p00 + (size_t)side * side, p11 = p10 + side;
+    // the brick's slot, then the eight taps inside the brick (17^3 floats: the +1 taps never leave it).  Bricks that are not tabulated
+    // read slot 0 against Err = +inf: the margin below is infinite and nothing is certified.
+    const uint32_t nbk = side >> 4;
+    const uint32_t slot = ((const uint32_t __attribute__((address_space(1))) *)F.brick)[__umul24(__umul24(ix >> 4, nbk) + (iy >> 4), nbk) + (iz >> 4)];
+    gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)slot * kBrickFloats + (((ix & 15u) * kBrickRow + (iy & 15u)) * kBrickRow + (iz & 15u)));
+    gfloat_p p01 = p00 + kBrickRow, p10 = p00 + kBrickRow * kBrickRow, p11 = p10 + kBrickRow;
     const float a000 = p00[0], a001 = p00[1], a010 = p01[0], a011 = p01[1];
     const float a100 = p10[0], a101 = p10[1], a110 = p11[0], a111 = p11[1];
     const float c00 = __builtin_fmaf(a001 - a000, wz, a000), c01 = __builtin_fmaf(a011 - a010, wz, a010);
@@ -779,27 +950,34 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(kFastBlock) k_guide_selfcheck(c
     else { A0 = A1 = A2 = 0.5f; }
     const V3 p = F.R * u;
     const V4 ex = coop_noise3d<false>(M, T, lds, valid, p, M.seed, F.R, A0, A1, A2);
-    float g, err;
+    float g, err, amax;
     const V3 pg = p / F.R;   // the grid point the exact evaluator used
-    const bool ok = valid && guide_lookup(F, pg, g, err);
+    const bool ok = valid && guide_lookup(F, pg, g, err, amax);
     float ratio = 0.f;
-    unsigned long long bad = 0, cnt = 0;
+    unsigned long long bad = 0, cnt = 0, tab = 0;
     float es = 0.f;
     if (ok) {
-        ratio = fabsf(ex.v - g) / err;
-        bad = ratio > 1.0f ? 1 : 0;
+        // everywhere in the field: the block's bound amax on |N| (level 0 of the certificate); in tabulated bricks also |N - G| <= Err
         cnt = 1;
-        es = err;
+        bad = fabsf(ex.v) > amax ? 1 : 0;
+        if (err < 3e38f) {
+            tab = 1;
+            ratio = fabsf(ex.v - g) / err;
+            bad |= ratio > 1.0f ? 1 : 0;
+            es = err;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         bad += __shfl_down(bad, off, 64);
         cnt += __shfl_down(cnt, off, 64);
+        tab += __shfl_down(tab, off, 64);
         ratio = fmaxf(ratio, __shfl_down(ratio, off, 64));
         es += __shfl_down(es, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&stats[0], cnt);
         atomicAdd(&stats[1], bad);
+        atomicAdd(&stats[3], tab);
         atomicMax((unsigned int *)ratio_max, __float_as_uint(ratio));   // non-negative floats order like their bits
         atomicAdd(err_sum, es);
     }
@@ -874,11 +1052,13 @@ inline void guide_free(GuideField *F)
 {
     if (F->G) (void)hipFree(F->G);
     if (F->err) (void)hipFree(F->err);
-    F->G = nullptr; F->err = nullptr; F->enabled = 0;
+    if (F->brick) (void)hipFree(F->brick);
+    F->G = nullptr; F->err = nullptr; F->brick = nullptr; F->enabled = 0; F->n_alloc = 0; F->n_usable = 0;
 }
 
-// Builds the guide field for the grid space of medium M (world space or isotropic-ray space).
-inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTable &T, int half, int ppc, GuideField *F)
+// Builds the guide field for the grid space of medium M (world space or isotropic-ray space).  `sparse`: tabulate only the bricks
+// level 1 of the certificate can be asked about (a 4x coarser field, built first, bounds |N| per brick); otherwise every brick.
+inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTable &T, int half, int ppc, GuideField *F, bool sparse = true)
 {
     guide_free(F);
     if (!fast_supported(M) || half < 2 || half > 64 || (ppc != 8 && ppc != 16 && ppc != 32 && ppc != 64))
@@ -891,18 +1071,51 @@ inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTab
         F->R = M.radius_iso;
         for (int a = 0; a < 3; ++a) F->alpha[a] = 0.5f * F->R * F->R;
     }
-    const size_t npts = (size_t)F->side * F->side * F->side;
-    const size_t nblk = npts / 64;
-    if (hipMalloc(&F->G, npts * sizeof(float)) != hipSuccess) { F->G = nullptr; (void)hipGetLastError(); return GPIS_ERR_DEVICE; }
-    if (hipMalloc(&F->err, 2 * nblk * sizeof(float)) != hipSuccess) { F->err = nullptr; guide_free(F); (void)hipGetLastError(); return GPIS_ERR_DEVICE; }
-    const size_t per_launch = (size_t)1 << 22;   // slabs of 4 Mi blocks
-    for (size_t b0 = 0; b0 < nblk; b0 += per_launch) {
-        const size_t nb = nblk - b0 < per_launch ? nblk - b0 : per_launch;
-        k_guide_build<0><<<(unsigned)nb, 64>>>(d_model, T, *F, b0);
+    const size_t nblk = ((size_t)F->side / 4) * (F->side / 4) * (F->side / 4);
+    const uint32_t nbricks = (uint32_t)(nblk / 64);
+    const unsigned bgrid = (nbricks + 255u) / 256u;
+    uint8_t *need = nullptr;
+    uint32_t *slot_of = nullptr, *list = nullptr, *counters = nullptr;
+    GuideField C{};
+    auto fail = [&](int code) {
+        (void)hipGetLastError();
+        if (need) (void)hipFree(need);
+        if (slot_of) (void)hipFree(slot_of);
+        if (list) (void)hipFree(list);
+        if (counters) (void)hipFree(counters);
+        guide_free(&C);
+        guide_free(F);
+        return code;
+    };
+    if (hipMalloc(&F->err, 2 * nblk * sizeof(float)) != hipSuccess) { F->err = nullptr; return fail(GPIS_ERR_DEVICE); }
+    if (hipMalloc(&F->brick, (size_t)nbricks * 4) != hipSuccess) { F->brick = nullptr; return fail(GPIS_ERR_DEVICE); }
+    if (hipMalloc(&need, nbricks) != hipSuccess || hipMalloc(&slot_of, (size_t)nbricks * 4) != hipSuccess || hipMalloc(&list, (size_t)nbricks * 4) != hipSuccess ||
+        hipMalloc(&counters, 8) != hipSuccess || hipMemset(counters, 0, 8) != hipSuccess)
+        return fail(GPIS_ERR_DEVICE);
+    // 1. which bricks does level 1 need?  (a-priori bound on |N| per brick from the field at ppc / 4: its 4-point block = this brick)
+    if (sparse && ppc >= 32) {
+        const int st = guide_build(M, d_model, T, half, ppc / 4, &C, false);
+        if (st != GPIS_OK) return fail(st);
     }
-    for (size_t b0 = 0; b0 < nblk; b0 += (size_t)1 << 30)     // second pass: the blocks' bounds on |N| (reads every sample of the field)
-        k_guide_amax<0><<<(unsigned)(((nblk - b0 < ((size_t)1 << 30) ? nblk - b0 : ((size_t)1 << 30)) + 255) / 256), 256>>>(*F, b0, nblk);
-    if (hipDeviceSynchronize() != hipSuccess) { guide_free(F); return GPIS_ERR_DEVICE; }
+    k_guide_need<0><<<bgrid, 256>>>(d_model, *F, C.err, need);
+    k_guide_slots<0><<<bgrid, 256>>>(*F, need, slot_of, list, counters);
+    uint32_t cnt[2] = {0, 0};
+    if (hipMemcpy(cnt, counters, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(GPIS_ERR_DEVICE);
+    guide_free(&C);
+    F->n_alloc = cnt[0]; F->n_usable = cnt[1];
+    // 2. the samples of the allocated bricks (at least one brick exists: the lookup table points unused bricks at slot 0)
+    const size_t pool = (size_t)(cnt[0] ? cnt[0] : 1u) * kBrickFloats;
+    if (hipMalloc(&F->G, pool * sizeof(float)) != hipSuccess) { F->G = nullptr; return fail(GPIS_ERR_DEVICE); }
+    if (!cnt[0] && hipMemset(F->G, 0, pool * sizeof(float)) != hipSuccess) return fail(GPIS_ERR_DEVICE);
+    const size_t n_items = (size_t)cnt[0] * 64, per_launch = (size_t)1 << 22;   // slabs of 4 Mi blocks
+    for (size_t i0 = 0; i0 < n_items; i0 += per_launch)
+        k_guide_build<0><<<(unsigned)(n_items - i0 < per_launch ? n_items - i0 : per_launch), 64>>>(d_model, T, *F, i0, list, slot_of, need);
+    // 3. the blocks' bounds on |N| (reads the samples incl. the shared layers), the lookup table
+    for (size_t i0 = 0; i0 < n_items; i0 += (size_t)1 << 30)
+        k_guide_amax<0><<<(unsigned)(((n_items - i0 < ((size_t)1 << 30) ? n_items - i0 : ((size_t)1 << 30)) + 255) / 256), 256>>>(*F, i0, n_items, list, need);
+    k_guide_table<0><<<bgrid, 256>>>(*F, need, slot_of);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(GPIS_ERR_DEVICE);
+    (void)hipFree(need); (void)hipFree(slot_of); (void)hipFree(list); (void)hipFree(counters);
     F->enabled = 1;
     return GPIS_OK;
 }

@@ -102,6 +102,7 @@ struct gpis_medium {
     FastTable fast;          // single-realization wave-cooperative path (gpis_fast.hpp); enabled == 0 when unused
     GuideField guide;        // certified guide field (gpis_guide.hpp); enabled == 0 until gpis_build_guide
     unsigned long long *d_guide_cnt;
+    uint64_t selfcheck_tabulated = 0;   // points of the last gpis_guide_selfcheck that fell into tabulated bricks
     GuideField *d_guide;     // device copy of `guide` (the resident guided kernels read it through scalar loads instead of 14 kernel-argument SGPRs)
     void *fs_ws = nullptr;            // function-space workspace: one FsGlob per resident workgroup (gpis_fs.hpp)
     unsigned fs_ws_blocks = 0;
@@ -974,9 +975,9 @@ extern "C" const char *gpis_abi_sizes(void)
     static char buf[512];
     snprintf(buf, sizeof buf,
              "gpis_params=%zu,gpis_mean=%zu,gpis_ray_in=%zu,gpis_seg_out=%zu,gpis_cond_coeff=%zu,gpis_query=%zu,"
-             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu,gpis_surface_s=%zu,gpis_ramp=%zu,gpis_fs_state=%zu",
+             "gpis_nee_query=%zu,gpis_derived=%zu,gpis_scene_s=%zu,gpis_surface_s=%zu,gpis_ramp=%zu,gpis_fs_state=%zu,gpis_guide_info=%zu",
              sizeof(gpis_params), sizeof(gpis_mean), sizeof(gpis_ray_in), sizeof(gpis_seg_out), sizeof(gpis_cond_coeff),
-             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s), sizeof(gpis_surface_s), sizeof(gpis_ramp), sizeof(gpis_fs_state));
+             sizeof(gpis_query), sizeof(gpis_nee_query), sizeof(gpis_derived), sizeof(gpis_scene_s), sizeof(gpis_surface_s), sizeof(gpis_ramp), sizeof(gpis_fs_state), sizeof(gpis_guide_info));
     return buf;
 }
 
@@ -1082,8 +1083,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     if (st != GPIS_OK) { delete m; return st; }
     hipError_t e = hipMalloc(&m->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&m->d_counters, 2 * sizeof(Counters));
-    if (e == hipSuccess) e = hipMalloc(&m->d_guide_cnt, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(m->d_guide_cnt, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&m->d_guide_cnt, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(m->d_guide_cnt, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&m->d_guide, sizeof(GuideField));
     if (e == hipSuccess) e = hipMemset(m->d_guide, 0, sizeof(GuideField));
     if (e == hipSuccess) e = hipMalloc(&m->d_next, kPersistSlots * sizeof(unsigned int));
@@ -1829,7 +1830,7 @@ extern "C" int gpis_reset_counters(gpis_medium *m)
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(m->d_counters, 0, 2 * sizeof(Counters)));
-    HIP_TRY(hipMemset(m->d_guide_cnt, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(m->d_guide_cnt, 0, 8 * sizeof(unsigned long long)));
     for (int k = 0; k < 3; ++k) { m->events_used[k] = 0; m->prof_ms[k] = 0.; m->prof_launches[k] = 0; }
     return GPIS_OK;
 }
@@ -1843,7 +1844,7 @@ extern "C" int gpis_build_guide(gpis_medium *m, int half_extent_cells, int point
     HIP_TRY(hipDeviceSynchronize());
     if (!m->fast.enabled)
         return set_err(GPIS_ERR_UNSUPPORTED, "gpis_build_guide: the medium is not covered by the wave-cooperative path (single_realization, 3D, stationary SE, diagonal anisotropy)");
-    int st = launch::guide_build(m->host_model, m->d_model, m->fast, half_extent_cells, points_per_cell, &m->guide);
+    int st = launch::guide_build(m->host_model, m->d_model, m->fast, half_extent_cells, points_per_cell, &m->guide, getenv("GPIS_GUIDE_DENSE") == nullptr);
     if (st != GPIS_OK)
         return set_err(st, "gpis_build_guide(half=%d, ppc=%d) failed: %s", half_extent_cells, points_per_cell,
                        st == GPIS_ERR_UNSUPPORTED ? "unsupported arguments" : hipGetErrorString(hipGetLastError()));
@@ -1876,22 +1877,38 @@ extern "C" int gpis_guide_selfcheck(gpis_medium *m, size_t n, const float *point
     CHECK_ARGS(m && (n == 0 || points3));
     if (!m->guide.enabled) return set_err(GPIS_ERR_UNSUPPORTED, "gpis_guide_selfcheck: no guide field built");
     HIP_TRY(hipSetDevice(m->device));
-    // scratch: [1..2] = checked/violations, word 3 = {max ratio bits, sum of bounds}
+    // scratch: [0] = points inside the field, [1] = violations, word 2 = {max ratio bits, sum of bounds}, [3] = points in tabulated bricks
     unsigned long long *st = m->d_guide_cnt + 1;
-    HIP_TRY(hipMemsetAsync(st, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(st, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
     if (n)
         launch::guide_selfcheck(m->d_model, m->fast, m->guide, n, points3, st, (float *)(st + 2), (float *)(st + 2) + 1, (hipStream_t)stream);
     int rc = launch_check("k_guide_selfcheck");
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    unsigned long long h[3];
+    unsigned long long h[4];
     HIP_TRY(hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost));
     float fr[2];
     memcpy(fr, &h[2], sizeof fr);
     if (checked) *checked = h[0];
     if (violations) *violations = h[1];
     if (max_ratio) *max_ratio = fr[0];
-    if (mean_bound) *mean_bound = h[0] ? fr[1] / (float)h[0] : 0.f;
+    if (mean_bound) *mean_bound = h[3] ? fr[1] / (float)h[3] : 0.f;
+    m->selfcheck_tabulated = h[3];
+    return GPIS_OK;
+}
+extern "C" int gpis_get_guide_info(gpis_medium *m, gpis_guide_info *out)
+{
+    CHECK_ARGS(m && out);
+    memset(out, 0, sizeof *out);
+    if (!m->guide.enabled) return GPIS_OK;
+    const GuideField &F = m->guide;
+    const uint64_t nblk = (uint64_t)(F.side / 4) * (F.side / 4) * (F.side / 4);
+    out->half_extent_cells = F.half; out->points_per_cell = F.ppc;
+    out->bricks_total = nblk / 64; out->bricks_allocated = F.n_alloc; out->bricks_usable = F.n_usable;
+    out->bytes_samples = (uint64_t)(F.n_alloc ? F.n_alloc : 1u) * kBrickFloats * 4;
+    out->bytes_bounds = nblk * 8 + (nblk / 64) * 4;
+    out->bytes_dense = (uint64_t)F.side * F.side * F.side * 4;
+    out->selfcheck_points_tabulated = m->selfcheck_tabulated;
     return GPIS_OK;
 }
 

@@ -47,7 +47,7 @@ void fast_transmittance(const DevModel *d_model, const FastTable &T, size_t n, c
                         Counters *cnt, hipStream_t s);
 int fast_stats_read(unsigned long long *out32);                 // GPIS_FAST_STATS builds only; GPIS_ERR_UNSUPPORTED otherwise
 // ---- certified guide field (tu_guide_build.hip: build + checks; tu_guided_sd.hip / tu_guided_tr.hip: the resident guided march) -----
-int guide_build(const DevModel &M, const DevModel *d_model, const FastTable &T, int half, int ppc, GuideField *F);
+int guide_build(const DevModel &M, const DevModel *d_model, const FastTable &T, int half, int ppc, GuideField *F, bool sparse);
 void guide_selfcheck(const DevModel *d_model, const FastTable &T, const GuideField &F, size_t n, const float *points3, unsigned long long *stats,
                      float *max_ratio, float *sum_bound, hipStream_t s);
 void guide_raycheck(const DevModel *d_model, const FastTable &T, const GuideField &F, size_t n, const gpis_ray_in *rays, uint32_t steps,

@@ -6,9 +6,9 @@
 
 namespace gpis { namespace launch {
 
-int guide_build(const DevModel &M, const DevModel *d_model, const FastTable &T, int half, int ppc, GuideField *F)
+int guide_build(const DevModel &M, const DevModel *d_model, const FastTable &T, int half, int ppc, GuideField *F, bool sparse)
 {
-    return gpis::guide_build(M, d_model, T, half, ppc, F);
+    return gpis::guide_build(M, d_model, T, half, ppc, F, sparse);
 }
 void guide_selfcheck(const DevModel *d_model, const FastTable &T, const GuideField &F, size_t n, const float *points3, unsigned long long *stats,
                      float *max_ratio, float *sum_bound, hipStream_t s)

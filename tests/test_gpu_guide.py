@@ -19,20 +19,39 @@ def _cluster_points(rng, n_groups, half):
     return pts.reshape(-1, 3).astype(np.float32)
 
 
-@pytest.mark.parametrize("cfg,ppc", [("C1", 32), ("C1", 8), ("C0", 16)])
-def test_guide_bound_holds(pkg, cfg, ppc):
-    import torch
+@pytest.mark.parametrize("cfg,ppc,dense", [("C1", 32, False), ("C1", 32, True), ("C1", 8, False), ("C0", 16, False), ("C1", 64, False)])
+def test_guide_bound_holds(pkg, cfg, ppc, dense):
+    """Both bounds of the certificate against the exact lattice sum on ~10^6 points: |N| <= amax in EVERY block of the field (level 0:
+    the sign of the mean decides), and |N - G| <= Err in the tabulated bricks (level 1).  The field is stored in bricks and only those
+    near the zero level set of the mean are tabulated (ppc >= 32; `dense` = GPIS_GUIDE_DENSE: every brick), so the mean's sphere is
+    shrunk to put the surface inside the 5-cell field of this test."""
+    import os
     half = 5
-    med = pkg.Medium(pkg.params_for_config(cfg))
-    med.build_guide(half, ppc)
+    params = pkg.params_for_config(cfg)
+    params["mean"]["radius"] = 0.32          # 3 of the field's 5 cells
+    med = pkg.Medium(params)
+    if dense:
+        os.environ["GPIS_GUIDE_DENSE"] = "1"
+    try:
+        med.build_guide(half, ppc)
+    finally:
+        os.environ.pop("GPIS_GUIDE_DENSE", None)
+    info = med.guide_info()
     rng = np.random.default_rng(7)
     pts = _cluster_points(rng, 16384, half)
     d = to_dev(pts)
     checked, bad, ratio, bound = med.guide_selfcheck(d.data_ptr(), len(pts))
-    print("guide %s ppc=%d: checked %d, violations %d, max |err|/bound %.3f, mean bound %.3f" % (cfg, ppc, checked, bad, ratio, bound))
+    tab = med.guide_info()["selfcheck_points_tabulated"]
+    print("guide %s ppc=%d%s: %d of %d bricks tabulated (%.2f of %.2f GB), checked %d (%d in tabulated bricks), violations %d, max |err|/bound %.3f, mean bound %.3f" % (
+        cfg, ppc, " dense" if dense else "", info["bricks_allocated"], info["bricks_total"], info["bytes_samples"] / 1e9, info["bytes_dense"] / 1e9,
+        checked, tab, bad, ratio, bound))
     assert checked > 0.95 * len(pts)
     assert bad == 0 and ratio < 1.0
-    assert 0 < bound < 50
+    assert 0 < bound < 50 and tab > 0.05 * checked
+    if dense or ppc < 32:
+        assert info["bricks_allocated"] == info["bricks_total"] and tab == checked
+    else:
+        assert info["bricks_usable"] < 0.8 * info["bricks_total"] and info["bricks_usable"] <= info["bricks_allocated"]
 
 
 def _far_bundle(rng, template, dist, n=256):
@@ -98,8 +117,14 @@ def test_headline_guide_configuration_16_64(pkg, ob):
     pts = _cluster_points(rng, 16384, 16)
     d = to_dev(pts)
     checked, bad, ratio, bound = med.guide_selfcheck(d.data_ptr(), len(pts))
-    print("guide C1 16:64: checked %d, violations %d, max |err|/bound %.3f, mean bound %.3f" % (checked, bad, ratio, bound))
+    info = med.guide_info()
+    print("guide C1 16:64: %d of %d bricks tabulated = %.2f GB of samples + %.2f GB of bounds (dense: %.1f GB); checked %d (%d in tabulated bricks), "
+          "violations %d, max |err|/bound %.3f, mean bound %.3f" % (info["bricks_allocated"], info["bricks_total"], info["bytes_samples"] / 1e9,
+                                                                     info["bytes_bounds"] / 1e9, info["bytes_dense"] / 1e9, checked,
+                                                                     info["selfcheck_points_tabulated"], bad, ratio, bound))
     assert checked > 0.95 * len(pts) and bad == 0 and ratio < 1.0
+    assert info["selfcheck_points_tabulated"] > 0.02 * checked
+    assert info["bytes_samples"] + info["bytes_bounds"] <= 10e9          # the whole guide: <= 10 GB (34.4 + 1.1 GB as a dense grid)
     _raycheck_bundles(pkg, ob, med, orc, "C1", "16:64")
     scene = ob.default_scene_s(480, 270, 2)
     rays, us = scene_rays(ob, orc, scene, step=6)
