@@ -452,6 +452,8 @@ typedef enum gpis_option {
                                  //   pending evaluation; -1 (default) = derived from impulse_density
     GPIS_OPT_RANGE_LEN = 7,      // guided march (resident form): 0 (default) = one ray per lane per launch; > 0 = rays per wave with
                                  //   in-wave refill as segments finish (multiple of 64; measured slower on camera rays)
+    GPIS_OPT_DEFER_GRAD = 8,     // guided march (resident form): 0 (default) = the segment's gradient is evaluated at the end of the march kernel;
+                                 //   1 = by a second kernel over the pending records (measured: DESIGN.md 8, the spill experiment)
     GPIS_OPT_COUNT_
 } gpis_option;
 typedef enum gpis_march_form { GPIS_MARCH_FORM_AUTO = 0, GPIS_MARCH_FORM_RESIDENT = 1, GPIS_MARCH_FORM_WAVE = 2 } gpis_march_form;

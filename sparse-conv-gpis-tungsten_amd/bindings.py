@@ -548,7 +548,7 @@ class Medium:
     def set_batch_order(self, scattered):
         self.L.check(self.L.lib.gpis_set_batch_order(self.h, 1 if scattered else 0), "gpis_set_batch_order")
 
-    OPTIONS = {"march_form": 0, "wave_tail": 1, "paths_sort": 2, "paths_presort": 3, "chunk_log2": 4, "persistent": 5, "solo_max": 6, "range_len": 7}
+    OPTIONS = {"march_form": 0, "wave_tail": 1, "paths_sort": 2, "paths_presort": 3, "chunk_log2": 4, "persistent": 5, "solo_max": 6, "range_len": 7, "defer_grad": 8}
     MARCH_FORMS = {"auto": 0, "resident": 1, "wave": 2}
 
     def set_option(self, name, value):

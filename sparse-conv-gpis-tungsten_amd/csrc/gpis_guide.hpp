@@ -486,6 +486,7 @@ GPIS_DEV float mean_approx(const DevModel &M, V3 p, float perr, float &slack)
 //   X_FINAL   exact lastVal at farT (sampleDistance only), G_GRAD exact gradient, G_DONE
 // Exact evaluations are cooperative (coop_evaluate_value); parked lanes are served in clusters whose
 // grid cells span at most 2 per axis, so the evaluator always takes its coherent path.
+constexpr int32_t kSegPending = 0x7FFFFFF0;     // gpis_seg_out::ok of a record that waits for its gradient (k_guided_range_grad)
 enum GPhase : int { G_INIT = 0, G_MARCH = 1, X_F0 = 2, X_CUR = 3, X_PREV = 4, X_REFINE = 5, X_FINAL = 6, G_GRAD = 7, G_DONE = 8 };
 
 GPIS_DEV V3 grid_point(const DevModel &M, const GuideField &F, V3 p, const Frame &coord)
@@ -624,7 +625,10 @@ GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRa
     return 0;
 }
 
-template <bool WANT_SAMPLE, bool SMALLARG>
+// DEFER_GRAD (sampleDistance only; GPIS_OPT_DEFER_GRAD): the segment's gradient evaluation is left to a second kernel — the record is
+// written with ok = kSegPending and k_guided_range_grad completes it — so that the march kernel does not carry the gradient
+// evaluator (the spill experiment of DESIGN.md 8).
+template <bool WANT_SAMPLE, bool SMALLARG, bool DEFER_GRAD = false>
 GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideField &F, FastLds &lds, bool valid,
                            const gpis_ray_in *__restrict__ rayp, gpis_seg_out *out, bool &visible, uint32_t &n_eval, uint32_t &n_guide)
 {
@@ -856,7 +860,16 @@ GPIS_DEV void guided_march(const DevModel &M, const FastTable &T, const GuideFie
     const long long clk_g0 = FCLK();
     const bool want_grad = phase == G_GRAD;
     V3 g = v3(0.f, 0.f, 0.f);
-    {
+    if (DEFER_GRAD) {
+        if (valid && want_grad) {
+            out->t = t;
+            out->exited = hit ? 0 : 1;
+            out->last_val = last_val;
+            out->gp_id = gp;
+            out->ok = kSegPending;
+            return;
+        }
+    } else {
         V3d rdn = to_d(dir);
         { double inv = 1.0 / length_d(rdn); rdn.x *= inv; rdn.y *= inv; rdn.z *= inv; }
         const V3 pgq = to_f(ray_at(to_d(pos), rdn, t));
@@ -899,6 +912,32 @@ __global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_di
     uint32_t n_eval = 0, n_guide = 0;
     bool vis;
     guided_march<true, SMALLARG>(*Mp, T, *Fp, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval, n_guide);
+    if (valid && coeff) {
+        gpis_cond_coeff c;
+        memset(&c, 0, sizeof c);
+        c.n_evals = n_eval;
+        coeff[i] = c;
+    }
+    fast_flush_counters(cnt, n_eval, valid ? 1u : 0u);
+    unsigned long long gsum = n_guide;
+    for (int off = 32; off > 0; off >>= 1) gsum += __shfl_down(gsum, off, 64);
+    if ((threadIdx.x & 63) == 0 && gsum) atomicAdd(guide_cnt, gsum);
+}
+
+// the same march with the gradient evaluation deferred to k_guided_range_grad (GPIS_OPT_DEFER_GRAD)
+template <bool SMALLARG>
+__global__ void __launch_bounds__(kFastBlock, GPIS_GUIDE_OCC) k_guided_sample_distance_nograd(const DevModel *__restrict__ Mp, FastTable T, const GuideField *__restrict__ Fp, size_t n,
+                                                                                            const gpis_ray_in *__restrict__ rays, gpis_seg_out *__restrict__ out,
+                                                                                            gpis_cond_coeff *__restrict__ coeff, const uint8_t *__restrict__ mask,
+                                                                                            Counters *cnt, unsigned long long *guide_cnt)
+{
+    __shared__ FastLds lds;
+    fast_lds_init(lds);
+    size_t i = (size_t)blockIdx.x * kFastBlock + threadIdx.x;
+    const bool valid = i < n && (!mask || mask[i]);
+    uint32_t n_eval = 0, n_guide = 0;
+    bool vis;
+    guided_march<true, SMALLARG, true>(*Mp, T, *Fp, lds, valid, rays + (valid ? i : 0), out + (valid ? i : 0), vis, n_eval, n_guide);
     if (valid && coeff) {
         gpis_cond_coeff c;
         memset(&c, 0, sizeof c);

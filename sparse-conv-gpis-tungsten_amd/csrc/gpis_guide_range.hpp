@@ -24,7 +24,6 @@
 
 namespace gpis {
 
-constexpr int32_t kSegPending = 0x7FFFFFF0;     // gpis_seg_out::ok of a record that waits for its gradient
 constexpr int G_IDLE = 9;                       // no ray left in the wave's range (extends GPhase)
 
 #ifndef GPIS_RANGE_OCC

@@ -1070,6 +1070,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
         if (const char *e = getenv("GPIS_PERSIST")) m->opt[GPIS_OPT_PERSISTENT] = e[0] != '0';
         m->opt[GPIS_OPT_RANGE_LEN] = 0;       // measured on C1: refill breaks the depth coherence the cooperative evaluator lives on
         if (const char *e = getenv("GPIS_RANGE_LEN")) { long long v = atoll(e); m->opt[GPIS_OPT_RANGE_LEN] = v <= 0 ? 0 : ((v + 63) / 64) * 64; }
+        m->opt[GPIS_OPT_DEFER_GRAD] = 0;
+        if (const char *e = getenv("GPIS_DEFER_GRAD")) m->opt[GPIS_OPT_DEFER_GRAD] = e[0] != '0';
         m->opt[GPIS_OPT_SOLO_MAX] = -1;
         if (const char *e = getenv("GPIS_SOLO_MAX")) m->opt[GPIS_OPT_SOLO_MAX] = atoll(e);
         m->opt[GPIS_OPT_CHUNK_LOG2] = 0;
@@ -1358,6 +1360,13 @@ static int sample_distance_impl(gpis_medium *m, size_t n, const gpis_ray_in *ray
         return launch_check("k_guided_range_sd / k_guided_range_grad");
     }
     if (m->guide.enabled) {
+        if (m->opt[GPIS_OPT_DEFER_GRAD]) {
+            launch::guided_sample_distance_nograd(m->host_model.exp_arg_max < 100.f, m->d_model, m->fast, m->d_guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt, s);
+            int rc = launch_check("k_guided_sample_distance_nograd");
+            if (rc) return rc;
+            launch::range_grad(m->host_model.exp_arg_max < 100.f, m->d_model, m->fast, m->guide, n, rays, out, coeff, mask, m->d_counters, s);
+            return launch_check("k_guided_range_grad");
+        }
         launch::guided_sample_distance(m->host_model.exp_arg_max < 100.f, m->d_model, m->fast, m->d_guide, n, rays, out, coeff, mask, m->d_counters, m->d_guide_cnt, s);
         return launch_check("k_guided_sample_distance");
     }
@@ -1432,7 +1441,7 @@ extern "C" int gpis_set_option(gpis_medium *m, int option, long long value)
     switch (option) {
     case GPIS_OPT_MARCH_FORM: CHECK_ARGS(value >= GPIS_MARCH_FORM_AUTO && value <= GPIS_MARCH_FORM_WAVE); break;
     case GPIS_OPT_WAVE_TAIL: CHECK_ARGS(value >= 0); break;
-    case GPIS_OPT_PATHS_SORT: case GPIS_OPT_PATHS_PRESORT: case GPIS_OPT_PERSISTENT: CHECK_ARGS(value == 0 || value == 1); break;
+    case GPIS_OPT_PATHS_SORT: case GPIS_OPT_PATHS_PRESORT: case GPIS_OPT_PERSISTENT: case GPIS_OPT_DEFER_GRAD: CHECK_ARGS(value == 0 || value == 1); break;
     case GPIS_OPT_CHUNK_LOG2: CHECK_ARGS(value == 0 || (value >= 16 && value <= 28)); break;
     case GPIS_OPT_SOLO_MAX: CHECK_ARGS(value >= -1 && value <= 64); break;
     case GPIS_OPT_RANGE_LEN: CHECK_ARGS(value >= 0 && value <= (1 << 24) && value % 64 == 0); break;

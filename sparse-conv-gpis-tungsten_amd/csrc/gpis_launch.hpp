@@ -54,6 +54,10 @@ void guide_raycheck(const DevModel *d_model, const FastTable &T, const GuideFiel
                     unsigned long long *stats, hipStream_t s);
 void guided_sample_distance(bool small_arg, const DevModel *d_model, const FastTable &T, const GuideField *d_guide, size_t n, const gpis_ray_in *rays,
                             gpis_seg_out *out, gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, unsigned long long *guide_cnt, hipStream_t s);
+void guided_sample_distance_nograd(bool small_arg, const DevModel *d_model, const FastTable &T, const GuideField *d_guide, size_t n, const gpis_ray_in *rays,
+                                   gpis_seg_out *out, gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, unsigned long long *guide_cnt, hipStream_t s);
+void range_grad(bool small_arg, const DevModel *d_model, const FastTable &T, const GuideField &F, size_t n, const gpis_ray_in *rays, gpis_seg_out *out,
+                gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, hipStream_t s);      // completes the records a *_nograd / range march left pending
 void guided_transmittance(bool small_arg, const DevModel *d_model, const FastTable &T, const GuideField *d_guide, size_t n, const gpis_ray_in *rays,
                           uint8_t *visible, const uint8_t *mask, Counters *cnt, unsigned long long *guide_cnt, hipStream_t s);
 // ---- guided march with in-wave refill from a range of the batch (tu_range.hip; off by default) ------------------

@@ -12,6 +12,12 @@ void guided_sample_distance(bool small_arg, const DevModel *d_model, const FastT
     if (small_arg) k_guided_sample_distance<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, d_guide, n, rays, out, coeff, mask, cnt, guide_cnt);
     else k_guided_sample_distance<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, d_guide, n, rays, out, coeff, mask, cnt, guide_cnt);
 }
+void guided_sample_distance_nograd(bool small_arg, const DevModel *d_model, const FastTable &T, const GuideField *d_guide, size_t n, const gpis_ray_in *rays,
+                                   gpis_seg_out *out, gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, unsigned long long *guide_cnt, hipStream_t s)
+{
+    if (small_arg) k_guided_sample_distance_nograd<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, d_guide, n, rays, out, coeff, mask, cnt, guide_cnt);
+    else k_guided_sample_distance_nograd<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, d_guide, n, rays, out, coeff, mask, cnt, guide_cnt);
+}
 int fast_stats_read(unsigned long long *out32)
 {
 #ifdef GPIS_FAST_STATS

@@ -20,6 +20,12 @@ void range_sample_distance(bool small_arg, const DevModel *d_model, const FastTa
     if (small_arg) k_guided_range_grad<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, F, n, rays, out, coeff, mask, cnt);
     else k_guided_range_grad<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, F, n, rays, out, coeff, mask, cnt);
 }
+void range_grad(bool small_arg, const DevModel *d_model, const FastTable &T, const GuideField &F, size_t n, const gpis_ray_in *rays, gpis_seg_out *out,
+                gpis_cond_coeff *coeff, const uint8_t *mask, Counters *cnt, hipStream_t s)
+{
+    if (small_arg) k_guided_range_grad<true><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, F, n, rays, out, coeff, mask, cnt);
+    else k_guided_range_grad<false><<<grid_of(n, kFastBlock), kFastBlock, 0, s>>>(d_model, T, F, n, rays, out, coeff, mask, cnt);
+}
 void range_transmittance(bool small_arg, const DevModel *d_model, const FastTable &T, const GuideField &F, size_t n, const gpis_ray_in *rays,
                          uint8_t *visible, const uint8_t *mask, Counters *cnt, unsigned long long *guide_cnt, uint32_t range_len, hipStream_t s)
 {

@@ -24,7 +24,9 @@ def main():
     W, H = (int(x) for x in (sys.argv[1:3] if len(sys.argv) > 2 else (256, 144)))
     params = pkg.params_for_config("C4")
     med = pkg.Medium(params)
-    orc = ob.Oracle(params, threads=os.cpu_count() or 1)
+    import bench
+    cores = bench.usable_cores()           # the cgroup's CPU share (16 on the GPU box), not the 256 logical CPUs of the host
+    orc = ob.Oracle(params, threads=cores)
     scene = ob.default_scene_s(W, H, 1)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from gpu_util import scene_rays
@@ -72,7 +74,7 @@ def main():
         "segments": n, "unit": "segments/s",
         "gpu_first_segments_per_s": n / dt1, "gpu_conditioned_segments_per_s": n / dt2,
         "hit_fraction_first": float((out1["exited"] == 0).mean()), "ok_fraction_second": float((out2["ok"] == 1).mean()),
-        "cpu_port": {"cores": os.cpu_count(), "sample": m, "first_segments_per_s": m / c1, "conditioned_segments_per_s": m / c2},
+        "cpu_port": {"cores": cores, "sample": m, "first_segments_per_s": m / c1, "conditioned_segments_per_s": m / c2},
         "kernel": "k_fs_march (one wave per segment, four segments per CU: 37 KB LDS + 104 KB L2-resident workspace each, fp64)"}))
 
 
