@@ -284,6 +284,8 @@ def main():
     fence()
     t_cold0 = time.perf_counter()
     med = pkg.Medium(params, device=local_rank)
+    torch.cuda.synchronize()
+    t_created = time.perf_counter()
     lib = med.L.lib
     guide_info = None
     if args.guide != "off" and int(med.derived()["fast_path"]):
@@ -316,9 +318,13 @@ def main():
         rank_stats.append(pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard,
                                                   sync=torch.cuda.synchronize))
 
+    torch.cuda.synchronize()
+    t_first0 = time.perf_counter()
     step()
     fence()
     dt_cold = time.perf_counter() - t_cold0
+    cold_parts = {"create_s": t_created - t_cold0, "guide_build_s": guide_info["build_s"] if guide_info else 0.0,
+                  "first_frame_s": time.perf_counter() - t_first0}      # the first frame allocates the driver's workspace (50 GB for C1)
 
     # ---- warm frames: the metric
     for _ in range(args.warmup):
@@ -425,6 +431,7 @@ def main():
                                        "fast (wave-cooperative)") if fast else ("per-path: persistent refilling march" if persistent else "per-path: one ray per lane"),
                        "guide": guide_info,
                        "value_cold_doc": "one frame with gpis_create (cell table), the guide-field build and the workspace allocation inside the timer (%.2f s)" % dt_cold_max,
+                       "value_cold_parts": cold_parts,
                        "value_unguided_doc": "one frame after gpis_drop_guide: every march step is an exact wave-cooperative evaluation" if dt_unguided else None},
             "roofline": roof,
             "per_rank": None if world == 1 else {

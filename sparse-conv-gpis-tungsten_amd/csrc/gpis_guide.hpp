@@ -50,8 +50,9 @@ constexpr uint32_t kBrickRow = 17, kBrickFloats = 17u * 17u * 17u;
 constexpr uint32_t kNoBrick = 0xFFFFFFFFu;
 struct GuideField {
     float *G;            // pool of tabulated bricks: slot * 17^3 + (lx * 17 + ly) * 17 + lz
-    float *err;          // (side/4)^3 blocks x 2, dense: the bound Err of the block (+inf where the brick is not tabulated), and amax = a bound on |N| anywhere in the block's cells
-    uint32_t *brick;     // (side/16)^3 bricks: slot of the brick's samples in the pool (slot 0 where not tabulated: Err = +inf makes its taps irrelevant)
+    uint64_t *blk;       // (side/4)^3 block records, dense, 8 bytes = one load per march step: slot << 32 | fp16 Err << 16 | fp16 amax (both
+                         // rounded UP; Err = the bound of the block, +inf where the brick is not tabulated; amax = a bound on |N| anywhere in
+                         // the block's cells; slot = the block's brick in the pool, 0 where not tabulated: Err = +inf makes its taps irrelevant)
     int half;            // extent in cells: u in [-half, half)
     int ppc;             // grid points per cell (h = 1/ppc)
     int side;            // 2*half*ppc
@@ -60,6 +61,20 @@ struct GuideField {
     int enabled;
     uint32_t n_alloc, n_usable;   // bricks in the pool / bricks level 1 may use
 };
+
+// bounds are stored as fp16 rounded towards +inf (values >= 0 or +inf)
+GPIS_DEV uint32_t guide_f2h_up(float x)
+{
+    _Float16 h = (_Float16)x;
+    uint32_t bits = (uint32_t)__builtin_bit_cast(unsigned short, h);
+    if ((float)h < x) bits += 1u;          // next fp16 up (the largest finite value steps to +inf)
+    return bits;
+}
+GPIS_DEV float guide_h2f(uint32_t bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(bits & 0xFFFFu)); }
+GPIS_DEV float guide_rec_amax(uint64_t r) { return guide_h2f((uint32_t)r); }
+GPIS_DEV float guide_rec_err(uint64_t r) { return guide_h2f((uint32_t)r >> 16); }
+GPIS_DEV uint32_t guide_rec_slot(uint64_t r) { return (uint32_t)(r >> 32); }
+GPIS_DEV uint64_t guide_rec_make(uint32_t slot, uint32_t err16, uint32_t amax16) { return ((uint64_t)slot << 32) | (uint64_t)((err16 << 16) | (amax16 & 0xFFFFu)); }
 
 #ifndef GPIS_GUIDE_OCC
 // waves per SIMD the guided kernels are register-allocated for.  Guide lookups are latency-bound, so
@@ -238,8 +253,10 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(64) k_guide_build(const DevMode
     }
     float emax = err;
     for (int off = 32; off > 0; off >>= 1) emax = fmaxf(emax, __shfl_xor(emax, off, 64));
-    if (lane == 0 && need[brick])
-        F.err[2 * (((size_t)bx * bs + (size_t)by) * bs + (size_t)bz)] = emax;
+    if (lane == 0 && need[brick]) {
+        uint64_t &r = F.blk[((size_t)bx * bs + (size_t)by) * bs + (size_t)bz];
+        r = guide_rec_make(guide_rec_slot(r), guide_f2h_up(emax), (uint32_t)r);
+    }
 }
 
 // Second pass of the build: amax(block) = max |V| over the corners of every cell anchored in the block (5x5x5 grid points: the last
@@ -273,7 +290,8 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_amax(GuideField F,
         }
     }
     const size_t b = ((size_t)bx * bs + (size_t)by) * bs + (size_t)bz;
-    F.err[2 * b + 1] = m + F.err[2 * b];
+    const uint64_t r = F.blk[b];
+    F.blk[b] = guide_rec_make(slot, (uint32_t)r >> 16, guide_f2h_up(m + guide_rec_err(r)));     // from here on level 1 may use the block
 }
 
 // Which bricks can level 1 be asked about?  One thread per brick: the block records of the brick get the a-priori pair (Err = +inf,
@@ -282,7 +300,7 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_amax(GuideField F,
 // of the grid space: in world-space sampling a box of world points (p = R u), in isotropic-ray space — where every ray sees the lattice
 // through its own rotation — the shell of world points with |W p| = R |u|, W = diag (no anisoMtx on this path).  Interval bounds per
 // mean type; the CSG minimum of two means takes the minimum of the bounds.  `coarse` == nullptr: every brick is needed (small fields).
-GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_need(const DevModel *__restrict__ Mp, GuideField F, const float *__restrict__ coarse_err, uint8_t *__restrict__ need)
+GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_need(const DevModel *__restrict__ Mp, GuideField F, const uint64_t *__restrict__ coarse_blk, uint8_t *__restrict__ need)
 {
     const uint32_t nbk = (uint32_t)F.side / kBrick, brick = blockIdx.x * 256u + threadIdx.x;
     if (brick >= nbk * nbk * nbk)
@@ -292,8 +310,8 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_need(const DevMode
     const uint32_t bs = (uint32_t)F.side / 4;
     bool needed = true;
     float amax = __builtin_huge_valf();
-    if (coarse_err) {
-        amax = coarse_err[2 * (size_t)brick + 1];
+    if (coarse_blk) {
+        amax = guide_rec_amax(coarse_blk[brick]);
         const float h = 1.0f / (float)F.ppc, pad = 2e-3f;
         float lo[3], hi[3];                                       // the brick's cells in grid units, padded
         const uint32_t kk[3] = {kx, ky, kz};
@@ -357,8 +375,7 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_need(const DevMode
     // default records of the brick's 64 blocks: level 1 certifies nothing (Err = +inf), level 0 uses the a-priori bound
     for (uint32_t s = 0; s < 64; ++s) {
         const size_t b = ((size_t)(4 * kx + (s >> 4)) * bs + (size_t)(4 * ky + ((s >> 2) & 3))) * bs + (size_t)(4 * kz + (s & 3));
-        F.err[2 * b] = __builtin_huge_valf();
-        F.err[2 * b + 1] = amax;
+        F.blk[b] = guide_rec_make(0u, 0x7C00u, guide_f2h_up(amax));
     }
 }
 // Allocation: a brick gets samples when it is needed or completes the shared layer of a needed brick before it (one of the seven
@@ -385,15 +402,6 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_slots(GuideField F
     }
     slot_of[brick] = slot;
 }
-// the lookup table of the finished field: the slot for the bricks level 1 may use, slot 0 for the rest (their Err is +inf)
-GPIS_TU_KERNEL __global__ void __launch_bounds__(256) k_guide_table(GuideField F, const uint8_t *__restrict__ need, const uint32_t *__restrict__ slot_of)
-{
-    const uint32_t nbk = (uint32_t)F.side / kBrick, brick = blockIdx.x * 256u + threadIdx.x;
-    if (brick >= nbk * nbk * nbk)
-        return;
-    F.brick[brick] = need[brick] ? slot_of[brick] : 0u;
-}
-
 // G and the bound at index-space coordinates (tx, ty, tz) = (u + half) * ppc; false outside the
 // tabulated volume
 GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float tz, float &g, float &err, float &amax);
@@ -424,9 +432,11 @@ GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float 
     const float wx = tx - fx0, wy = ty - fy0, wz = tz - fz0;
     // side <= 8192 (guide_build): ix*side + iy < 2^26 is a 24-bit multiply-add, the element index one 32x32->64 multiply-add
     // (as size_t arithmetic on ints this was 30 instructions of sign extensions and 64x64 multiplies per march step)
-    // the brick's slot (side <= 8192: nbk <= 512, the brick index is a 24-bit multiply-add), then the eight taps inside the brick
-    const uint32_t nbk = side >> 4;
-    const uint32_t slot = ((const uint32_t __attribute__((address_space(1))) *)F.brick)[__umul24(__umul24(ix >> 4, nbk) + (iy >> 4), nbk) + (iz >> 4)];
+    // the block's record (bounds + the slot of its brick), then the eight taps inside the brick
+    const uint32_t bs = side >> 2;
+    const uint32_t brow = __umul24(ix >> 2, bs) + (iy >> 2);
+    const uint64_t rec = ((const uint64_t __attribute__((address_space(1))) *)F.blk)[(uint64_t)brow * bs + (iz >> 2)];
+    const uint32_t slot = guide_rec_slot(rec);
     gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)slot * kBrickFloats + (((ix & 15u) * kBrickRow + (iy & 15u)) * kBrickRow + (iz & 15u)));
     gfloat_p p01 = p00 + kBrickRow, p10 = p00 + kBrickRow * kBrickRow, p11 = p10 + kBrickRow;
     const float a000 = p00[0], a001 = p00[1], a010 = p01[0], a011 = p01[1];
@@ -436,11 +446,8 @@ GPIS_DEV bool guide_lookup_index(const GuideField &F, float tx, float ty, float 
     const float c10 = __builtin_fmaf(a101 - a100, wz, a100), c11 = __builtin_fmaf(a111 - a110, wz, a110);
     const float c0 = __builtin_fmaf(c01 - c00, wy, c00), c1 = __builtin_fmaf(c11 - c10, wy, c10);
     g = __builtin_fmaf(c1 - c0, wx, c0);
-    const uint32_t bs = side >> 2;
-    const uint32_t brow = __umul24(ix >> 2, bs) + (iy >> 2);
-    gfloat_p pe = (gfloat_p)F.err + 2u * ((uint64_t)brow * bs + (iz >> 2));
-    err = pe[0];                      // +inf where the brick is not tabulated (g is then some other brick's value: never used against a finite bound)
-    amax = pe[1];
+    err = guide_rec_err(rec);         // +inf where the brick is not tabulated (g is then some other brick's value: never used against a finite bound)
+    amax = guide_rec_amax(rec);
     return true;
 }
 
@@ -592,8 +599,8 @@ GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRa
         return 0;
     const uint32_t bs = side >> 2;
     const uint32_t brow = __umul24(ix >> 2, bs) + (iy >> 2);
-    gfloat_p pe = (gfloat_p)__builtin_assume_aligned(F.err, 8) + 2u * ((uint64_t)brow * bs + (iz >> 2));
-    const float e_err = pe[0], e_amax = pe[1];                                   // (Err, amax) of the block: one 8-byte load
+    const uint64_t rec = ((const uint64_t __attribute__((address_space(1))) *)__builtin_assume_aligned(F.blk, 8))[(uint64_t)brow * bs + (iz >> 2)];   // one 8-byte load
+    const float e_amax = guide_rec_amax(rec);
     const V3 p = v3(__builtin_fmaf(tf, gr.dir.x, gr.pos.x), __builtin_fmaf(tf, gr.dir.y, gr.pos.y), __builtin_fmaf(tf, gr.dir.z, gr.pos.z));
     float ms;
     const float mean = mean_approx(M, p, __builtin_fmaf(fabsf(tf), gr.pe1, gr.pe0), ms);
@@ -601,13 +608,12 @@ GPIS_DEV int guide_sign_at(const DevModel &M, const GuideField &F, const GuideRa
     if (fabsf(mean) > e_amax * gr.sn * 1.0001f + ms + 4e-6f * fabsf(mean) + 1e-7f)
         return mean > 0.f ? 1 : -1;
     // level 1
-    if (!(e_err < 3e38f))
-        return 0;                    // the brick is not tabulated: nothing to certify with (the exact evaluation decides)
+    if (((uint32_t)rec >> 16) == 0x7C00u)
+        return 0;                    // Err = +inf: the brick is not tabulated, nothing to certify with (the exact evaluation decides)
+    const float e_err = guide_rec_err(rec);
     const float wx = tx - fx0, wy = ty - fy0, wz = tz - fz0;
-    // the brick's slot, then the eight taps inside the brick (17^3 floats: the +1 taps never leave it).  Bricks that are not tabulated
-    // read slot 0 against Err = +inf: the margin below is infinite and nothing is certified.
-    const uint32_t nbk = side >> 4;
-    const uint32_t slot = ((const uint32_t __attribute__((address_space(1))) *)F.brick)[__umul24(__umul24(ix >> 4, nbk) + (iy >> 4), nbk) + (iz >> 4)];
+    // the eight taps inside the block's brick (17^3 floats: the +1 taps never leave it)
+    const uint32_t slot = guide_rec_slot(rec);
     gfloat_p p00 = (gfloat_p)F.G + ((uint64_t)slot * kBrickFloats + (((ix & 15u) * kBrickRow + (iy & 15u)) * kBrickRow + (iz & 15u)));
     gfloat_p p01 = p00 + kBrickRow, p10 = p00 + kBrickRow * kBrickRow, p11 = p10 + kBrickRow;
     const float a000 = p00[0], a001 = p00[1], a010 = p01[0], a011 = p01[1];
@@ -1090,9 +1096,8 @@ GPIS_TU_KERNEL __global__ void __launch_bounds__(kFastBlock) k_guide_raycheck(co
 inline void guide_free(GuideField *F)
 {
     if (F->G) (void)hipFree(F->G);
-    if (F->err) (void)hipFree(F->err);
-    if (F->brick) (void)hipFree(F->brick);
-    F->G = nullptr; F->err = nullptr; F->brick = nullptr; F->enabled = 0; F->n_alloc = 0; F->n_usable = 0;
+    if (F->blk) (void)hipFree(F->blk);
+    F->G = nullptr; F->blk = nullptr; F->enabled = 0; F->n_alloc = 0; F->n_usable = 0;
 }
 
 // Builds the guide field for the grid space of medium M (world space or isotropic-ray space).  `sparse`: tabulate only the bricks
@@ -1126,8 +1131,7 @@ inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTab
         guide_free(F);
         return code;
     };
-    if (hipMalloc(&F->err, 2 * nblk * sizeof(float)) != hipSuccess) { F->err = nullptr; return fail(GPIS_ERR_DEVICE); }
-    if (hipMalloc(&F->brick, (size_t)nbricks * 4) != hipSuccess) { F->brick = nullptr; return fail(GPIS_ERR_DEVICE); }
+    if (hipMalloc(&F->blk, nblk * sizeof(uint64_t)) != hipSuccess) { F->blk = nullptr; return fail(GPIS_ERR_DEVICE); }
     if (hipMalloc(&need, nbricks) != hipSuccess || hipMalloc(&slot_of, (size_t)nbricks * 4) != hipSuccess || hipMalloc(&list, (size_t)nbricks * 4) != hipSuccess ||
         hipMalloc(&counters, 8) != hipSuccess || hipMemset(counters, 0, 8) != hipSuccess)
         return fail(GPIS_ERR_DEVICE);
@@ -1136,7 +1140,7 @@ inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTab
         const int st = guide_build(M, d_model, T, half, ppc / 4, &C, false);
         if (st != GPIS_OK) return fail(st);
     }
-    k_guide_need<0><<<bgrid, 256>>>(d_model, *F, C.err, need);
+    k_guide_need<0><<<bgrid, 256>>>(d_model, *F, C.blk, need);
     k_guide_slots<0><<<bgrid, 256>>>(*F, need, slot_of, list, counters);
     uint32_t cnt[2] = {0, 0};
     if (hipMemcpy(cnt, counters, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(GPIS_ERR_DEVICE);
@@ -1149,10 +1153,9 @@ inline int guide_build(const DevModel &M, const DevModel *d_model, const FastTab
     const size_t n_items = (size_t)cnt[0] * 64, per_launch = (size_t)1 << 22;   // slabs of 4 Mi blocks
     for (size_t i0 = 0; i0 < n_items; i0 += per_launch)
         k_guide_build<0><<<(unsigned)(n_items - i0 < per_launch ? n_items - i0 : per_launch), 64>>>(d_model, T, *F, i0, list, slot_of, need);
-    // 3. the blocks' bounds on |N| (reads the samples incl. the shared layers), the lookup table
+    // 3. the blocks' bounds on |N| (reads the samples incl. the shared layers) and their bricks' slots
     for (size_t i0 = 0; i0 < n_items; i0 += (size_t)1 << 30)
         k_guide_amax<0><<<(unsigned)(((n_items - i0 < ((size_t)1 << 30) ? n_items - i0 : ((size_t)1 << 30)) + 255) / 256), 256>>>(*F, i0, n_items, list, need);
-    k_guide_table<0><<<bgrid, 256>>>(*F, need, slot_of);
     if (hipDeviceSynchronize() != hipSuccess) return fail(GPIS_ERR_DEVICE);
     (void)hipFree(need); (void)hipFree(slot_of); (void)hipFree(list); (void)hipFree(counters);
     F->enabled = 1;

@@ -1915,7 +1915,7 @@ extern "C" int gpis_get_guide_info(gpis_medium *m, gpis_guide_info *out)
     out->half_extent_cells = F.half; out->points_per_cell = F.ppc;
     out->bricks_total = nblk / 64; out->bricks_allocated = F.n_alloc; out->bricks_usable = F.n_usable;
     out->bytes_samples = (uint64_t)(F.n_alloc ? F.n_alloc : 1u) * kBrickFloats * 4;
-    out->bytes_bounds = nblk * 8 + (nblk / 64) * 4;
+    out->bytes_bounds = nblk * 8;
     out->bytes_dense = (uint64_t)F.side * F.side * F.side * 4;
     out->selfcheck_points_tabulated = m->selfcheck_tabulated;
     return GPIS_OK;
