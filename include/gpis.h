@@ -390,6 +390,14 @@ int gpis_fs_transmittance_host(gpis_medium *m, size_t n, const gpis_ray_in *rays
 typedef enum gpis_fs_linalg_op { GPIS_FS_OP_EIGH = 0, GPIS_FS_OP_NORM_TRANSFORM = 1, GPIS_FS_OP_PINV = 2 } gpis_fs_linalg_op;
 int gpis_fs_linalg_batch(gpis_medium *m, int op, int n, size_t count, const double *in, double *out, double *evals, void *stream);
 
+/* Test surface of csrc/gpis_libm.hpp, the device's bit-for-bit restatement of the host libm (glibc 2.35, x86-64 with FMA) for the
+ * double-precision functions this path calls: out[i] = fn(x[i]) (fn(x[i], y[i]) for GPIS_LIBM_POW; sin -> out, cos -> out2 for
+ * GPIS_LIBM_SINCOS; GPIS_LIBM_LOGF rounds x to float first and widens the result).  Device pointers; y and out2 may be NULL where
+ * unused.  Needs no medium handle; runs on the current device. */
+typedef enum gpis_libm_fn { GPIS_LIBM_EXP = 0, GPIS_LIBM_LOG = 1, GPIS_LIBM_LOGF = 2, GPIS_LIBM_SIN = 3, GPIS_LIBM_COS = 4, GPIS_LIBM_SINCOS = 5,
+                            GPIS_LIBM_POW = 6 } gpis_libm_fn;
+int gpis_libm_batch(int fn, size_t n, const double *x, const double *y, double *out, double *out2, void *stream);
+
 /* Bit-exact primitives (MathUtil.hpp:179-224, UniformSampler.hpp:41-75, BitManip.hpp:47-50):
  * out[i] = xxhash32 of `arity` (1..4) words at words[i*arity..]; and the PCG32 stream
  * after set_state(state[i]) — `count` raw nextI() draws each. */

@@ -242,7 +242,10 @@ static inline v3f mult3(const float *a, v3f b)
 
 /* Box–Muller, Gaussian.cpp:21-34; PI is the float constant of Angle.hpp:8 */
 static const float PI_F = 3.1415926536f;
-static inline void rand_normal_2(pcg32 *s, double *z1, double *z2)
+/* not inlined, as in the reference (a function of Gaussian.cpp called from other translation units): both outputs are always
+ * computed, so a gcc build always merges the cos and the sin into one sincos() call — which in glibc 2.35 has no FMA variant and
+ * differs in the last bit from cos() / sin() on a fraction of the arguments.  csrc/gpis_libm.hpp mirrors that on the device. */
+static __attribute__((noinline)) void rand_normal_2(pcg32 *s, double *z1, double *z2)
 {
     double u1 = pcg_next_1d(s);
     double u2 = pcg_next_1d(s);

@@ -272,7 +272,7 @@ class GpisLib:
         "gpis_sample_distance_batch", "gpis_transmittance_batch", "gpis_eval_value_batch",
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
         "gpis_xxhash32_batch", "gpis_pcg32_stream_batch", "gpis_mean_color_emission_batch", "gpis_mean_color_emission_host",
-        "gpis_fs_sample_distance_batch", "gpis_fs_transmittance_batch", "gpis_fs_linalg_batch",
+        "gpis_fs_sample_distance_batch", "gpis_fs_transmittance_batch", "gpis_fs_linalg_batch", "gpis_libm_batch",
         "gpis_fs_sample_distance_host", "gpis_fs_transmittance_host",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
@@ -314,6 +314,7 @@ class GpisLib:
         L.gpis_nee_grad_batch.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_mean_color_emission_batch.argtypes = [vp, sz, vp, vp, vp, vp]
         L.gpis_fs_linalg_batch.argtypes = [vp, i32, i32, sz, vp, vp, vp, vp]
+        L.gpis_libm_batch.argtypes = [i32, sz, vp, vp, vp, vp, vp]
         L.gpis_fs_sample_distance_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_fs_transmittance_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_mean_color_emission_host.argtypes = [vp, sz, vp, vp, vp]
@@ -370,6 +371,26 @@ def load_library(path=None):
     if _LIB is None or (path and _LIB.path != path):
         _LIB = GpisLib(path)
     return _LIB
+
+
+LIBM_FNS = {"exp": 0, "log": 1, "logf": 2, "sin": 3, "cos": 4, "sincos": 5, "pow": 6}
+
+
+def libm_eval(fn, x, y=None, device=0, lib=None):
+    """Test surface: the device's restatement of the host libm (csrc/gpis_libm.hpp) applied to the array x (and y for "pow");
+    returns the results as float64 ("sincos": the pair)."""
+    import torch
+    L = lib or load_library()
+    dev = torch.device("cuda", device)
+    torch.cuda.set_device(dev)
+    d_x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+    d_y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(dev) if y is not None else None
+    d_o, d_o2 = torch.zeros_like(d_x), torch.zeros_like(d_x)
+    torch.cuda.synchronize(dev)
+    L.check(L.lib.gpis_libm_batch(LIBM_FNS[fn], d_x.numel(), ctypes.c_void_p(d_x.data_ptr()), ctypes.c_void_p(d_y.data_ptr()) if d_y is not None else None,
+                                  ctypes.c_void_p(d_o.data_ptr()), ctypes.c_void_p(d_o2.data_ptr()), None), "gpis_libm_batch")
+    torch.cuda.synchronize(dev)
+    return (d_o.cpu().numpy(), d_o2.cpu().numpy()) if fn == "sincos" else d_o.cpu().numpy()
 
 
 class Medium:

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "gpis.h"
+#include "gpis_libm.hpp"
 
 #pragma clang fp contract(off)
 
@@ -47,7 +48,7 @@ GPIS_DEV double ramp_unit(double coord, double scale, double offset, double la, 
     double u = coord * scale + offset;
     u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
     double l = la * (1.0 - u) + lb * u;
-    return sqrt(exp(l));
+    return sqrt(exp_glibc(l));
 }
 struct DevModel {
     // flags (SCNM.cpp:57-73, SCN.cpp:21-30)
@@ -242,7 +243,7 @@ static __device__ __attribute__((noinline)) float sdf_simplex3d(float px, float 
 {
     auto dot3 = [](float ax, float ay, float az, float bx, float by, float bz) { float r = ax * bx; r += ay * by; r += az * bz; return r; };
     auto random3 = [&](float cx, float cy, float cz, float &rx, float &ry, float &rz) {        // SdfFunctions.cpp:199-208
-        float j = (float)(4096.0 * sin((double)dot3(cx, cy, cz, 17.0f, 59.4f, 15.0f)));
+        float j = (float)(4096.0 * sin_glibc((double)dot3(cx, cy, cz, 17.0f, 59.4f, 15.0f)));
         double v;
         v = 512.0 * (double)j; rz = (float)(v - floor(v));
         j = (float)((double)j * .125);
@@ -349,7 +350,7 @@ static __device__ __attribute__((noinline)) void bessel_k01(double x, double *k0
 {
     const double EULER = 0.57721566490153286061;
     if (x <= 2.0) {
-        const double q = 0.25 * x * x, lg = log(0.5 * x);
+        const double q = 0.25 * x * x, lg = log_glibc(0.5 * x);
         double term0 = 1.0, i0 = 1.0, s0 = 0.0, hk = 0.0;           /* term0 = q^k / (k!)^2 */
         double term1 = 1.0, i1s = 1.0, s1 = 1.0 - 2.0 * EULER;       /* term1 = q^k / (k! (k+1)!), s1 = sum (psi(k+1) + psi(k+2)) term1 */
         double hk1 = 1.0;                                            /* H_{k+1} */
@@ -387,7 +388,7 @@ static __device__ __attribute__((noinline)) void bessel_k01(double x, double *k0
             if (fabs(dels / s) < 1e-17) break;
         }
         h = a1 * h;
-        const double rk0 = sqrt(3.14159265358979323846 / (2.0 * x)) * exp(-x) / s;
+        const double rk0 = sqrt(3.14159265358979323846 / (2.0 * x)) * exp_glibc(-x) / s;
         *k0 = rk0;
         *k1 = rk0 * (x + 0.5 - h) / x;
     }
@@ -475,11 +476,13 @@ GPIS_DEV void rand_normal_2(Pcg32 &s, double &z1, double &z2)
 {
     double u1 = (double)normalized_uint(s.next_i());
     double u2 = (double)normalized_uint(s.next_i());
-    double r = sqrt(-2 * log(1. - u1));
+    double r = sqrt(-2 * log_glibc(1. - u1));
     const float two_pi = 2 * 3.1415926536f;
     double ang = (double)two_pi * u2;
-    z1 = r * cos(ang);
-    z2 = r * sin(ang);
+    double sn, cs;                       // rand_normal_2 takes both, which a gcc build turns into one sincos call (gpis_libm.hpp)
+    sincos_glibc(ang, &sn, &cs);
+    z1 = r * cs;
+    z2 = r * sn;
 }
 
 // ---------------------------------------------------------------------------------------

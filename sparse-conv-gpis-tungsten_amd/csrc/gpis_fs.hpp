@@ -68,7 +68,7 @@ GPIS_DEV double fs_cov(const DevModel &M, int da, int db, V3d a, V3d b, V3d dirA
     const V3d ad{an.x * d.x, an.y * d.y, an.z * d.z};
     const double absq = fs_dot(d, ad);
     const float s2 = M.sigma_raw * M.sigma_raw, l2 = M.k_l * M.k_l;
-    const double c = (double)s2 * exp(-absq / (double)(2 * l2));
+    const double c = (double)s2 * exp_glibc(-absq / (double)(2 * l2));
     if (da == FS_NONE && db == FS_NONE)
         return c;
     if (da == FS_FIRST && db == FS_NONE)
@@ -515,7 +515,7 @@ GPIS_DEV double fs_rand_truncated_normal(double mean, double sigma, double a, Pc
     double x_bar = 0.0;
     for (int i = 0; i < 1000; i++) {
         const double u = fs_next1d(s);
-        x_bar = sqrt(a_bar * a_bar - 2 * log(1 - u));
+        x_bar = sqrt(a_bar * a_bar - 2 * log_glibc(1 - u));
         const double v = fs_next1d(s);
         if (v < x_bar / a_bar) break;
     }

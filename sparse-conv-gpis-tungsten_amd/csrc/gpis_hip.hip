@@ -1551,6 +1551,13 @@ extern "C" int gpis_fs_linalg_batch(gpis_medium *m, int op, int n, size_t count,
     launch::fs_linalg((unsigned)(count < cap ? count : cap), op, n, count, in, out, evals, m->fs_ws, (hipStream_t)stream);
     return launch_check("k_fs_linalg");
 }
+extern "C" int gpis_libm_batch(int fn, size_t n, const double *x, const double *y, double *out, double *out2, void *stream)
+{
+    CHECK_ARGS(fn >= GPIS_LIBM_EXP && fn <= GPIS_LIBM_POW && (n == 0 || (x && out)) && (fn != GPIS_LIBM_POW || n == 0 || y) && (fn != GPIS_LIBM_SINCOS || n == 0 || out2));
+    if (n == 0) return GPIS_OK;
+    launch::libm_eval(fn, n, x, y, out, out2, (hipStream_t)stream);
+    return launch_check("k_libm");
+}
 extern "C" int gpis_fs_sample_distance_batch(gpis_medium *m, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out, void *stream)
 {
     CHECK_ARGS(m && (n == 0 || (rays && states && out)));

@@ -90,6 +90,7 @@ size_t fs_workspace_bytes_per_block();
 void fs_march(bool want_sample, unsigned grid, const DevModel *d_model, size_t n, const gpis_ray_in *rays, gpis_fs_state *states, gpis_seg_out *out,
               uint8_t *visible, void *workspace, hipStream_t s);
 int fs_prof_read(unsigned long long *out16, int reset);         // GPIS_FS_PROF builds only
+void libm_eval(int fn, size_t n, const double *x, const double *y, double *out, double *out2, hipStream_t s);   // test surface (tu_libm.hip)
 void fs_linalg(unsigned grid, int op, int n, size_t count, const double *in, double *out, double *evals, void *workspace, hipStream_t s);   // test surface
 inline unsigned grid_of(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
