@@ -392,10 +392,10 @@ int gpis_fs_linalg_batch(gpis_medium *m, int op, int n, size_t count, const doub
 
 /* Test surface of csrc/gpis_libm.hpp, the device's bit-for-bit restatement of the host libm (glibc 2.35, x86-64 with FMA) for the
  * double-precision functions this path calls: out[i] = fn(x[i]) (fn(x[i], y[i]) for GPIS_LIBM_POW; sin -> out, cos -> out2 for
- * GPIS_LIBM_SINCOS; GPIS_LIBM_LOGF rounds x to float first and widens the result).  Device pointers; y and out2 may be NULL where
+ * GPIS_LIBM_SINCOS and GPIS_LIBM_SINCOSF; GPIS_LIBM_LOGF and GPIS_LIBM_SINCOSF round x to float first and widen the results).  Device pointers; y and out2 may be NULL where
  * unused.  Needs no medium handle; runs on the current device. */
 typedef enum gpis_libm_fn { GPIS_LIBM_EXP = 0, GPIS_LIBM_LOG = 1, GPIS_LIBM_LOGF = 2, GPIS_LIBM_SIN = 3, GPIS_LIBM_COS = 4, GPIS_LIBM_SINCOS = 5,
-                            GPIS_LIBM_POW = 6 } gpis_libm_fn;
+                            GPIS_LIBM_POW = 6, GPIS_LIBM_SINCOSF = 7 } gpis_libm_fn;
 int gpis_libm_batch(int fn, size_t n, const double *x, const double *y, double *out, double *out2, void *stream);
 
 /* Bit-exact primitives (MathUtil.hpp:179-224, UniformSampler.hpp:41-75, BitManip.hpp:47-50):

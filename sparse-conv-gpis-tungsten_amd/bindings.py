@@ -373,7 +373,7 @@ def load_library(path=None):
     return _LIB
 
 
-LIBM_FNS = {"exp": 0, "log": 1, "logf": 2, "sin": 3, "cos": 4, "sincos": 5, "pow": 6}
+LIBM_FNS = {"exp": 0, "log": 1, "logf": 2, "sin": 3, "cos": 4, "sincos": 5, "pow": 6, "sincosf": 7}
 
 
 def libm_eval(fn, x, y=None, device=0, lib=None):
@@ -390,7 +390,7 @@ def libm_eval(fn, x, y=None, device=0, lib=None):
     L.check(L.lib.gpis_libm_batch(LIBM_FNS[fn], d_x.numel(), ctypes.c_void_p(d_x.data_ptr()), ctypes.c_void_p(d_y.data_ptr()) if d_y is not None else None,
                                   ctypes.c_void_p(d_o.data_ptr()), ctypes.c_void_p(d_o2.data_ptr()), None), "gpis_libm_batch")
     torch.cuda.synchronize(dev)
-    return (d_o.cpu().numpy(), d_o2.cpu().numpy()) if fn == "sincos" else d_o.cpu().numpy()
+    return (d_o.cpu().numpy(), d_o2.cpu().numpy()) if fn in ("sincos", "sincosf") else d_o.cpu().numpy()
 
 
 class Medium:

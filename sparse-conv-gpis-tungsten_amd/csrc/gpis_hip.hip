@@ -1553,7 +1553,7 @@ extern "C" int gpis_fs_linalg_batch(gpis_medium *m, int op, int n, size_t count,
 }
 extern "C" int gpis_libm_batch(int fn, size_t n, const double *x, const double *y, double *out, double *out2, void *stream)
 {
-    CHECK_ARGS(fn >= GPIS_LIBM_EXP && fn <= GPIS_LIBM_POW && (n == 0 || (x && out)) && (fn != GPIS_LIBM_POW || n == 0 || y) && (fn != GPIS_LIBM_SINCOS || n == 0 || out2));
+    CHECK_ARGS(fn >= GPIS_LIBM_EXP && fn <= GPIS_LIBM_SINCOSF && (n == 0 || (x && out)) && (fn != GPIS_LIBM_POW || n == 0 || y) && ((fn != GPIS_LIBM_SINCOS && fn != GPIS_LIBM_SINCOSF) || n == 0 || out2));
     if (n == 0) return GPIS_OK;
     launch::libm_eval(fn, n, x, y, out, out2, (hipStream_t)stream);
     return launch_check("k_libm");

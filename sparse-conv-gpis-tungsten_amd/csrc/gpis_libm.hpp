@@ -416,4 +416,45 @@ GPIS_LIBM_FN double pow_glibc(double x, double y)
     return __builtin_fma(scale, tm, scale);
 }
 
+// sincosf(float): glibc 2.35 sysdeps/x86/fpu/sincosf_poly.h + sysdeps/ieee754/flt-32/s_sincosf.c (ARM optimized-routines sincosf:
+// reduction by pi/2 and two short polynomials in double), FMA variant (__sincosf_fma; a cosf and a sinf of the same angle are one
+// sincosf call in a gcc build).  |y| < 120 is covered (the rotation angle of the anisotropy field is at most pi / 2); beyond it a
+// quiet NaN comes back.  Table: __sincosf_table ([1] = the coefficients for the quadrants where the cosine changes sign).
+GPIS_LIBM_TAB double kSinCosfTab[2][8] = {
+    {0x1.0000000000000p+0, -0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3, 0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, -0x1.6c087e89a359dp-10,
+     -0x1.994eb3774cf24p-13, 0x1.99343027bf8c3p-16},
+    {-0x1.0000000000000p+0, 0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3, -0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, 0x1.6c087e89a359dp-10,
+     -0x1.994eb3774cf24p-13, -0x1.99343027bf8c3p-16},
+};
+GPIS_LIBM_FN void libm_sincosf_poly(double x, double x2, int tab, int n, float *sinp, float *cosp)
+{
+    const double *T = kSinCosfTab[tab];           // c0, c1, {s1, c2}, {s2, c3}, {s3, c4}
+    const double x3 = x * x2, x4 = x2 * x2, x5 = x2 * x3, x6 = x2 * x4;
+    const double c1v = __builtin_fma(x2, T[1], T[0]);
+    const double sv = __builtin_fma(__builtin_fma(T[6], x2, T[4]), x5, __builtin_fma(x3, T[2], x));
+    const double cv = __builtin_fma(__builtin_fma(T[7], x2, T[5]), x6, __builtin_fma(x4, T[3], c1v));
+    if (n & 1) { *cosp = (float)sv; *sinp = (float)cv; }
+    else { *sinp = (float)sv; *cosp = (float)cv; }
+}
+GPIS_LIBM_FN void sincosf_glibc(float y, float *sinp, float *cosp)
+{
+    const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
+    const uint32_t top = (__builtin_bit_cast(uint32_t, y) >> 20) & 0x7ffu;
+    double x = (double)y;
+    if (top < 0x3f4u) {                                                       // |y| < pi / 4
+        if (top < 0x398u) { *sinp = y; *cosp = 1.0f; return; }                // |y| < 2^-12
+        libm_sincosf_poly(x, x * x, 0, 0, sinp, cosp);
+        return;
+    }
+    if (top < 0x42fu) {                                                       // |y| < 120
+        const double r = x * hpi_inv;
+        const int n = ((int32_t)r + 0x800000) >> 24;
+        x = __builtin_fma(-(double)n, hpi, x);
+        const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        libm_sincosf_poly(x * sgn, x * x, (n & 2) ? 1 : 0, n, sinp, cosp);
+        return;
+    }
+    *sinp = *cosp = __builtin_nanf("");
+}
+
 }   // namespace gpis

@@ -22,6 +22,7 @@ __global__ void __launch_bounds__(256) k_libm(int fn, size_t n, const double *x,
     case GPIS_LIBM_COS: out[i] = cos_glibc(a); break;
     case GPIS_LIBM_SINCOS: { double s, c; sincos_glibc(a, &s, &c); out[i] = s; out2[i] = c; break; }
     case GPIS_LIBM_POW: out[i] = pow_glibc(a, y[i]); break;
+    case GPIS_LIBM_SINCOSF: { float s, c; sincosf_glibc((float)a, &s, &c); out[i] = (double)s; out2[i] = (double)c; break; }
     default: out[i] = 0.0;
     }
 }

@@ -13,11 +13,12 @@ static inline bool same(double a, double b) { return libm_asu(a) == libm_asu(b) 
 int main(int argc, char **argv)
 {
     uint64_t s = 88172645463325252ull, n = argc > 1 ? strtoull(argv[1], 0, 10) : 20000000ull;
-    uint64_t bad_e = 0, bad_lf = 0, bad_l = 0, bad_s = 0, bad_c = 0, bad_sc = 0, bad_p = 0;
+    uint64_t bad_e = 0, bad_lf = 0, bad_l = 0, bad_s = 0, bad_c = 0, bad_sc = 0, bad_p = 0, bad_scf = 0;
     double (*volatile p_sin)(double) = std::sin;
     double (*volatile p_cos)(double) = std::cos;
     void (*volatile p_sincos)(double, double *, double *) = sincos;
     double (*volatile p_pow)(double, double) = std::pow;
+    void (*volatile p_sincosf)(float, float *, float *) = sincosf;
     for (uint64_t i = 0; i < n; ++i) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         const double u = (double)(s >> 11) * 0x1p-53;
@@ -51,6 +52,15 @@ int main(int argc, char **argv)
             sincos_glibc(xs, &s3, &c3);
             if (!same(s2, s3) || !same(c2, c3)) { if (bad_sc < 5) printf("sincos x=%a libm=%a %a mine=%a %a\n", xs, s2, c2, s3, c3); ++bad_sc; }
         }
+        float xsf;
+        switch (i & 3) { case 0: xsf = (float)(u * 1.5707963267948966); break; case 1: xsf = (float)((u - 0.5) * 12.0); break; case 2: xsf = (float)((u - 0.5) * 238.0); break;
+                         default: xsf = (float)std::exp(u * 30.0 - 28.0); break; }
+        {
+            float s4, c4, s5, c5;
+            p_sincosf(xsf, &s4, &c4);
+            sincosf_glibc(xsf, &s5, &c5);
+            if (fu(s4) != fu(s5) || fu(c4) != fu(c5)) { if (bad_scf < 5) printf("sincosf x=%a libm=%a %a mine=%a %a\n", xsf, s4, c4, s5, c5); ++bad_scf; }
+        }
         double xp, yp;
         switch (i & 7) { case 0: xp = u * 4.0 + 1e-6; yp = 3.0; break; case 1: xp = std::exp(u * 60.0 - 30.0); yp = 3.0; break; case 2: xp = u * 3.0 + 1e-9; yp = 2.0; break;
                          case 3: xp = (double)(float)(u * 2.5 + 0.01); yp = 3.0; break; case 4: xp = std::exp(u * 1400.0 - 700.0); yp = (double)((int)(s >> 3 & 7) - 3) + 0.5; break;
@@ -61,7 +71,7 @@ int main(int argc, char **argv)
             if (!same(ap, bp)) { if (bad_p < 5) printf("pow x=%a y=%a libm=%a mine=%a\n", xp, yp, ap, bp); ++bad_p; }
         }
     }
-    printf("%llu inputs each: exp %llu, logf %llu, log %llu, sin %llu, cos %llu, sincos %llu, pow %llu mismatches\n", (unsigned long long)n, (unsigned long long)bad_e,
-           (unsigned long long)bad_lf, (unsigned long long)bad_l, (unsigned long long)bad_s, (unsigned long long)bad_c, (unsigned long long)bad_sc, (unsigned long long)bad_p);
-    return (bad_e || bad_lf || bad_l || bad_s || bad_c || bad_sc || bad_p) ? 1 : 0;
+    printf("%llu inputs each: exp %llu, logf %llu, log %llu, sin %llu, cos %llu, sincos %llu, pow %llu, sincosf %llu mismatches\n", (unsigned long long)n, (unsigned long long)bad_e,
+           (unsigned long long)bad_lf, (unsigned long long)bad_l, (unsigned long long)bad_s, (unsigned long long)bad_c, (unsigned long long)bad_sc, (unsigned long long)bad_p, (unsigned long long)bad_scf);
+    return (bad_e || bad_lf || bad_l || bad_s || bad_c || bad_sc || bad_p || bad_scf) ? 1 : 0;
 }

@@ -108,7 +108,7 @@ def test_random_configuration(pkg, ob, seed):
     for k in d_g.dtype.names:
         if k != "fast_path":
             assert np.array_equal(np.asarray(d_g[k]), np.asarray(d_o[k]), equal_nan=True), k
-    exact = not int(params["sampling_1d"]) and not int(params["nonstationary"])
+    exact = True      # rounds 1-2: only the 3D stationary chain; the device now evaluates the host libm bit for bit (csrc/gpis_libm.hpp)
     # single-point entries: evaluateValue / evaluateGradient under random conditioning coefficients
     q = np.zeros(256, dtype=pkg.QUERY)
     q["p"] = rng.uniform(-1.3, 1.3, (256, 3)).astype(f32)

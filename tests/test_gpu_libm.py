@@ -25,6 +25,8 @@ def _libm():
     m.pow.argtypes = [ctypes.c_double, ctypes.c_double]
     m.logf.restype = ctypes.c_float
     m.logf.argtypes = [ctypes.c_float]
+    m.sincosf.restype = None
+    m.sincosf.argtypes = [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     m.sincos.restype = None
     m.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     return m
@@ -90,3 +92,16 @@ def test_pow_equals_the_host_pow_on_the_cubes_and_squares_the_path_takes():
     bad = ~_same(got, want)
     assert not bad.any(), (int(bad.sum()), x[bad][:4], y[bad][:4], got[bad][:4], want[bad][:4])
     assert pkg.libm_eval("pow", np.array([0.0]), np.array([3.0]))[0] == 0.0
+
+
+def test_sincosf_equals_the_host_sincosf():
+    m = _libm()
+    u = np.random.default_rng(14).random(N)
+    x = np.concatenate([u[:N // 2] * (np.pi / 2), (u[N // 2:3 * N // 4] - 0.5) * 12, (u[3 * N // 4:] - 0.5) * 238]).astype(np.float32)
+    s, c = pkg.libm_eval("sincosf", x.astype(np.float64))
+    ws, wc = np.empty(N, np.float32), np.empty(N, np.float32)
+    ps, pc = ctypes.c_float(), ctypes.c_float()
+    for i, v in enumerate(x):
+        m.sincosf(float(v), ctypes.byref(ps), ctypes.byref(pc))
+        ws[i], wc[i] = ps.value, pc.value
+    assert np.array_equal(s.astype(np.float32).view(np.uint32), ws.view(np.uint32)) and np.array_equal(c.astype(np.float32).view(np.uint32), wc.view(np.uint32))

@@ -16,7 +16,7 @@ from gpu_util import to_dev, dev_empty, to_host, stream_ptr, scene_rays, shadow_
 
 pytestmark = pytest.mark.gpu
 
-RTOL, ATOL = 2e-5, 2e-6
+RTOL, ATOL = 0.0, 0.0        # round 3: the device evaluates the host's libm bit for bit (csrc/gpis_libm.hpp): every comparison below is exact
 
 
 @pytest.fixture(scope="module")
@@ -300,7 +300,9 @@ def test_per_path_realizations_and_conditioning(env, ctx, iso):
 
 
 def _close(a, b, rtol=RTOL, atol=ATOL):
-    return np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+    """rounds 1-2 compared the media whose evaluation goes through double-precision libm within (rtol, atol); since round 3 the
+    device computes the host's libm results bit for bit, so the tolerances the call sites still name are ignored: equality."""
+    return np.array_equal(a, b, equal_nan=True)
 
 
 def _same(a, b):
@@ -333,7 +335,7 @@ def test_1d_sampling_and_nee(env, ctx, xy, scheme):
     sh = shadow_rays_from(ob, scene, rays, us, want[0])
     g2, w2 = med.sample_distance(sh, want_coeff=True), orc.sample_distance(sh, want_coeff=True)
     flips = int((g2[0]["exited"] != w2[0]["exited"]).sum())
-    assert flips <= max(1, len(sh) // 500), "hit/miss flips: %d of %d" % (flips, len(sh))
+    assert flips == 0, "hit/miss flips: %d of %d" % (flips, len(sh))
     same = g2[0]["exited"] == w2[0]["exited"]
     assert _close(g2[0]["t"][same], w2[0]["t"][same])
     assert _close(g2[1]["value_scale"], w2[1]["value_scale"]) and _close(g2[1]["gradient_scale"], w2[1]["gradient_scale"])
@@ -481,7 +483,7 @@ def test_c3_at_its_own_impulse_density(env):
     got, want = med.sample_distance(rays, want_coeff=True), orc.sample_distance(rays, want_coeff=True)
     flips = int((got[0]["exited"] != want[0]["exited"]).sum())
     print("C3 rho=64: %d rays, %d hit/miss flips" % (len(rays), flips))
-    assert flips <= max(1, len(rays) // 300)
+    assert flips == 0
     same = got[0]["exited"] == want[0]["exited"]
     assert _close(got[0]["t"][same], want[0]["t"][same], 1e-4, 1e-4)
     assert _close(got[0]["aniso"][same], want[0]["aniso"][same], 1e-3, 1e-3)
@@ -489,7 +491,7 @@ def test_c3_at_its_own_impulse_density(env):
     assert len(sh) > 20
     g2, w2 = med.sample_distance(sh, want_coeff=True), orc.sample_distance(sh, want_coeff=True)
     flips2 = int((g2[0]["exited"] != w2[0]["exited"]).sum())
-    assert flips2 <= max(1, len(sh) // 300)
+    assert flips2 == 0
     assert _close(g2[1]["value_scale"], w2[1]["value_scale"], 1e-3, 1e-4)
     assert (med.transmittance(sh) != orc.transmittance(sh)).sum() <= max(1, len(sh) // 300)
 
@@ -513,7 +515,7 @@ def test_multi_resolution_nonstationary(env, iso, oned):
     rays, us = scene_rays(ob, orc, scene, step=3)
     got, want = med.sample_distance(rays), orc.sample_distance(rays)
     flips = int((got["exited"] != want["exited"]).sum())
-    assert flips <= max(1, len(rays) // 300), "hit/miss flips: %d of %d" % (flips, len(rays))
+    assert flips == 0, "hit/miss flips: %d of %d" % (flips, len(rays))
     same = got["exited"] == want["exited"]
     assert _close(got["t"][same], want["t"][same], 1e-4, 1e-4)
 
@@ -552,7 +554,7 @@ def test_aniso_field(env, iso, multires, ctx):
     batch = np.concatenate([rays, sh])
     got, want = med.sample_distance(batch), orc.sample_distance(batch)
     flips = int((got["exited"] != want["exited"]).sum())
-    assert flips <= max(1, len(batch) // 300), "hit/miss flips: %d of %d" % (flips, len(batch))
+    assert flips == 0, "hit/miss flips: %d of %d" % (flips, len(batch))
     same = got["exited"] == want["exited"]
     assert _close(got["t"][same], want["t"][same], 1e-4, 1e-4)
     assert (med.transmittance(batch) != orc.transmittance(batch)).sum() <= max(1, len(batch) // 300)
@@ -600,7 +602,7 @@ def test_variance_field_btlr_color_emission(env, multires):
         med.set_option("persistent", persistent)
         got, want = med.sample_distance(rays), orc.sample_distance(rays)
         flips = int((got["exited"] != want["exited"]).sum())
-        assert flips <= max(1, len(rays) // 300), "hit/miss flips: %d of %d" % (flips, len(rays))
+        assert flips == 0, "hit/miss flips: %d of %d" % (flips, len(rays))
         same = (got["exited"] == want["exited"]) & (got["ok"] == want["ok"])
         assert _close(got["t"][same], want["t"][same], 1e-4, 1e-4)
         assert _close(got["weight"][same], want["weight"][same], 1e-4, 1e-5)
@@ -639,17 +641,17 @@ def test_sandstone_and_rust_noises(env, noise):
     pts = np.random.default_rng(5).uniform(-1.4, 1.4, (4096, 3))
     cg, eg = med.mean_color_emission(pts)
     co, eo = orc.mean_color_emission(pts)
-    close = np.isclose(cg, co, rtol=1e-6, atol=1e-6).all(axis=1) & np.isclose(eg, eo, rtol=1e-6, atol=1e-6).all(axis=1)
+    close = (cg == co).all(axis=1) & (eg == eo).all(axis=1)
     print("%s: colour / emission agree on %d of %d points, max |diff| elsewhere %.3g" % (noise, close.sum(), len(pts), np.abs(cg - co).max()))
-    assert close.mean() >= 0.995
+    assert close.all()
     assert (co[:, 0] != co[:, 2]).any() and co.min() >= 0.0 and co.max() <= 1.0        # a real vector field
     q = _queries(pkg, 1024, 72)
     vg, vo = med.eval_value(q)[0], orc.eval_value(q)[0]
-    ok = np.isclose(vg, vo, rtol=1e-4, atol=1e-5)
+    ok = vg == vo
     print("%s: evaluateValue agrees on %d of %d queries" % (noise, ok.sum(), len(q)))
-    assert ok.mean() >= 0.99
+    assert ok.all()
     gg, go = med.eval_gradient(q), orc.eval_gradient(q)
-    assert np.isclose(gg, go, rtol=2e-4, atol=2e-4).all(axis=1).mean() >= 0.99
+    assert np.array_equal(gg, go, equal_nan=True)
     scene = ob.default_scene_s(96, 54, 1)
     rays, us = scene_rays(ob, orc, scene, step=3)
     for persistent in (1, 0):                                       # both select the all-features lane-per-ray instance for these media
@@ -657,16 +659,16 @@ def test_sandstone_and_rust_noises(env, noise):
         got, want = med.sample_distance(rays), orc.sample_distance(rays)
         flips = int((got["exited"] != want["exited"]).sum())
         print("%s: %d hit/miss flips of %d segments" % (noise, flips, len(rays)))
-        assert flips <= max(2, len(rays) // 100), "hit/miss flips: %d of %d" % (flips, len(rays))
+        assert flips == 0, "hit/miss flips: %d of %d" % (flips, len(rays))
         same = (got["exited"] == want["exited"]) & (got["ok"] == want["ok"])
-        assert np.isclose(got["t"][same], want["t"][same], rtol=1e-4, atol=1e-4).mean() >= 0.98
+        assert np.array_equal(got["t"][same], want["t"][same])
     # the scalar flavour on its own ("var" only, stationary length scale)
     p2 = pkg.params_for_config("C3")
     p2["impulse_density"] = 12
     p2["ls_min"], p2["ls_max"] = 1.0, 1.0
     p2["var"]["enabled"], p2["var"]["type"], p2["var"]["min"], p2["var"]["max"] = 1, typ, 0.25, 2.0
     m2, o2 = pkg.Medium(p2), ob.Oracle(p2, threads=16)
-    assert np.isclose(m2.eval_value(q)[0], o2.eval_value(q)[0], rtol=1e-4, atol=1e-5).mean() >= 0.99
+    assert np.array_equal(m2.eval_value(q)[0], o2.eval_value(q)[0])
     assert not np.allclose(o2.eval_value(q)[0], orc.eval_value(q)[0])
 
 
@@ -703,7 +705,7 @@ def test_matern_and_gabor_kernels(env, kernel):
         med.set_option("persistent", persistent)
         got = med.sample_distance(batch, want_coeff=True)
         flips = int((got[0]["exited"] != want[0]["exited"]).sum())
-        assert flips <= max(1, len(batch) // 300), (kernel, persistent, flips, len(batch))
+        assert flips == 0, (kernel, persistent, flips, len(batch))
         same = got[0]["exited"] == want[0]["exited"]
         assert _close(got[0]["t"][same], want[0]["t"][same], 1e-4, 1e-4)
         assert _close(got[1]["value_scale"][same], want[1]["value_scale"][same], 1e-3, 1e-4)
@@ -935,8 +937,7 @@ def test_render_scene_s_nee(env, scheme):
     close = np.isclose(got, want, rtol=1e-3, atol=1e-6)
     print("scheme %d: sum gpu %.6f oracle %.6f, pixels outside tolerance %d, bitwise equal %d of %d" % (
         scheme, got.sum(), want.sum(), (~close).sum(), (got == want).sum(), got.size))
-    assert close.mean() >= 0.995
-    assert abs(float(got.sum()) - float(want.sum())) <= 1e-3 * float(want.sum())
+    assert np.array_equal(got, want), "pixels that differ: %d of %d" % ((got != want).sum(), got.size)
     bad = np.array(surf, dtype=pkg.SURFACE_S)
     bad["cap_cos"] = 1.0
     assert med.L.lib.gpis_render_scene_s_nee(med.h, sc.ctypes.data_as(ctypes.c_void_p), bad.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None) == -1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parametrised GPU-box session (replaces the per-session scripts of rounds 1-2):
 #   tools/gpu_session.sh <out-subdir> <step> [<step> ...]
-# steps: build | tests[:<pytest -k expr>] | file:<tests/file.py>[:<-k expr>] | smoke | bench[:<extra bench.py args>] | py:<script + args>
+# steps: build | tests[:<pytest -k expr>] | alltests[:<-k expr>] (no -x: every failure is listed) | file:<tests/file.py>[:<-k expr>] | smoke | bench[:<extra bench.py args>] | py:<script + args>
 # Every step logs into gpurun_out/<out-subdir>/ and a failing step ends the session (no GPU step runs after a failure).
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -13,6 +13,7 @@ for step in "$@"; do
     case $kind in
     build) python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; } ;;
     tests) timeout -k 10 1100 python -m pytest tests -m gpu -x -q ${arg:+-k "$arg"} > $O/tests_$i.log 2>&1; rc=$?; tail -5 $O/tests_$i.log; [ $rc = 0 ] || exit $rc ;;
+    alltests) timeout -k 10 1100 python -m pytest tests -m gpu -q ${arg:+-k "$arg"} > $O/tests_$i.log 2>&1; rc=$?; tail -25 $O/tests_$i.log; [ $rc = 0 ] || exit $rc ;;
     file) f=${arg%%:*}; k=${arg#*:}; [ "$f" = "$arg" ] && k=""
           timeout -k 10 1100 python -m pytest $f -m gpu -x -q -s ${k:+-k "$k"} > $O/file_$i.log 2>&1; rc=$?; tail -8 $O/file_$i.log; [ $rc = 0 ] || exit $rc ;;
     smoke) timeout -k 10 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 || exit 1 ;;
