@@ -240,18 +240,25 @@ static inline v3f mult3(const float *a, v3f b)
               M(a, 2, 0) * b.x + M(a, 2, 1) * b.y + M(a, 2, 2) * b.z);
 }
 
+/* Which libm entry a trigonometric call reaches is part of the result's last bit: glibc 2.35's sin() and cos() resolve to FMA
+ * variants on an x86-64 CPU with FMA, its sincos() has one SSE2 body, and gcc turns a sin and a cos of the same argument inside
+ * one function into one sincos() call.  The reference's functions are separate (virtual) functions, so what a gcc build of it calls
+ * is decided per function: rand_normal_2 and the two Gabor gradients take both (sincos), the two Gabor values take one (cos, sin).
+ * These helpers are not inlined, which pins the same choice here whatever the optimiser would do across the restatement's larger
+ * functions; csrc/gpis_libm.hpp restates the three entries for the device. */
+static __attribute__((noinline)) double libm_sin_alone(double x) { return sin(x); }
+static __attribute__((noinline)) double libm_cos_alone(double x) { return cos(x); }
+static __attribute__((noinline)) void libm_sin_and_cos(double x, double *sn, double *cs) { *sn = sin(x); *cs = cos(x); }
+
 /* Box–Muller, Gaussian.cpp:21-34; PI is the float constant of Angle.hpp:8 */
 static const float PI_F = 3.1415926536f;
-/* not inlined, as in the reference (a function of Gaussian.cpp called from other translation units): both outputs are always
- * computed, so a gcc build always merges the cos and the sin into one sincos() call — which in glibc 2.35 has no FMA variant and
- * differs in the last bit from cos() / sin() on a fraction of the arguments.  csrc/gpis_libm.hpp mirrors that on the device. */
-static __attribute__((noinline)) void rand_normal_2(pcg32 *s, double *z1, double *z2)
+static inline void rand_normal_2(pcg32 *s, double *z1, double *z2)
 {
     double u1 = pcg_next_1d(s);
     double u2 = pcg_next_1d(s);
     double r = sqrt(-2 * log(1. - u1));
-    double x = cos(2 * PI_F * u2);   /* 2*PI is float*int→float, then * double */
-    double y = sin(2 * PI_F * u2);
+    double x, y;                     /* 2*PI is float*int→float, then * double */
+    libm_sin_and_cos(2 * PI_F * u2, &y, &x);
     *z1 = r * x;
     *z2 = r * y;
 }
@@ -400,7 +407,7 @@ static inline float sdf_dot3(v3f a, v3f b) { float r = a.x * b.x; r += a.y * b.y
 static v3f sdf_random3(v3f c)                                  /* SdfFunctions.cpp:199-208 */
 {
     const v3f k = {17.0f, 59.4f, 15.0f};
-    float j = (float)(4096.0 * sin((double)sdf_dot3(c, k)));
+    float j = (float)(4096.0 * libm_sin_alone((double)sdf_dot3(c, k)));
     v3f r; double v;
     v = 512.0 * (double)j; r.z = (float)(v - floor(v));
     j = (float)((double)j * .125);
@@ -648,10 +655,12 @@ static v4f other_splat3d(const oracle_medium *m, v3f ab)
     if (m->P.kernel_type == GPIS_KERNEL_GABOR_ANISO) {                   /* GPF.cpp:1140-1150 */
         v3f om = v3(m->gabor_omega[0], m->gabor_omega[1], m->gabor_omega[2]);
         float od = v3_dot(om, ab);
-        float val = (float)(exp(-M_PI * (a * a) * v3_length_sq(ab)) * cos(2.f * M_PI * f * od));
+        double sph, cph;                                                 /* value: GPF.cpp:1140-1142 (cos alone); gradient: 1144-1150 (both) */
+        float val = (float)(exp(-M_PI * (a * a) * v3_length_sq(ab)) * libm_cos_alone(2.f * M_PI * f * od));
+        libm_sin_and_cos(2.f * M_PI * f * od, &sph, &cph);
         float A = (float)exp(-M_PI * (a * a) * v3_length_sq(ab));
-        float B = (float)cos(2.f * M_PI * f * od);
-        float c1 = -(float)(A * sin(2.f * M_PI * f * od) * 2.f * M_PI * f);
+        float B = (float)cph;
+        float c1 = -(float)(A * sph * 2.f * M_PI * f);
         float c2 = (float)(B * A * 2.f * M_PI * (a * a));
         v3f g = v3_sub(v3_scale(om, c1), v3_scale(ab, c2));
         return v4(val, g.x, g.y, g.z);
@@ -659,9 +668,11 @@ static v4f other_splat3d(const oracle_medium *m, v3f ab)
     {                                                                    /* GPF.cpp:1205-1214 */
         float r = sqrtf(v3_length_sq(ab));
         float ar = a * r;
-        float val = (float)(exp(-M_PI * (ar * ar)) * 2 * f / r * sin(2 * M_PI * f * r));
+        double s2, c2;                                                   /* value: sin alone; gradient: both */
+        float val = (float)(exp(-M_PI * (ar * ar)) * 2 * f / r * libm_sin_alone(2 * M_PI * f * r));
+        libm_sin_and_cos(2 * M_PI * f * r, &s2, &c2);
         float gs = (float)(2 * f * exp(-M_PI * (a * a) * v3_length_sq(ab)) *
-                           (-sin(2 * M_PI * f * r) / pow(r, 3) - 2 * M_PI * (a * a) * sin(2 * M_PI * f * r) / r + 2 * M_PI * f * cos(2 * M_PI * f * r) / (r * r)));
+                           (-s2 / pow(r, 3) - 2 * M_PI * (a * a) * s2 / r + 2 * M_PI * f * c2 / (r * r)));
         return v4(val, gs * ab.x, gs * ab.y, gs * ab.z);
     }
 }
