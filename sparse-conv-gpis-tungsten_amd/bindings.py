@@ -278,7 +278,7 @@ class GpisLib:
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
         "gpis_set_batch_order", "gpis_set_option", "gpis_get_option", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_info", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
-        "gpis_default_scene_s", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
+        "gpis_default_scene_s", "gpis_reserve_scene_workspace", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
     ]
 
     def __init__(self, path=None):
@@ -344,6 +344,7 @@ class GpisLib:
         L.gpis_guide_selfcheck.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
         L.gpis_guide_raycheck.argtypes = [vp, sz, vp, u32, vp, vp, vp]
         L.gpis_default_scene_s.argtypes = [vp, u32, u32, u32]
+        L.gpis_reserve_scene_workspace.argtypes = [vp, vp]
         L.gpis_default_scene_s.restype = None
         L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
         L.gpis_render_scene_s_paths.argtypes = [vp, vp, i32, ctypes.c_float, vp, vp]

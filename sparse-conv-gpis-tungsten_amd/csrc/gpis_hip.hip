@@ -107,8 +107,13 @@ struct gpis_medium {
     void *fs_ws = nullptr;            // function-space workspace: one FsGlob per resident workgroup (gpis_fs.hpp)
     unsigned fs_ws_blocks = 0;
     // staging for the *_host entries and workspace for the renderer (grown on demand)
-    void *stage[5];
-    size_t stage_bytes[5];
+    // slots 0-2: *_host staging; 3: renderer workspace (Lambert driver: primary rays + jitters + mask); 4: wavefront march;
+    // 5, 6: the Lambert driver's segment results and its shadow-ray arrays — separate allocations, so that each can be made while
+    // the kernel that does not need it yet runs (gpis_render_scene_s) or ahead of time from another thread (gpis_reserve_scene_workspace)
+    static constexpr int kStageSlots = 7;
+    void *stage[kStageSlots];
+    size_t stage_bytes[kStageSlots];
+    std::mutex stage_mu[kStageSlots];   // guards the growth of one slot (the reserve entry does not take `mu`)
     std::mutex mu;
     std::mutex fs_host_mu;   // serialises the function-space host entries, which own fs_stage[] end to end
     void *fs_stage[3] = {nullptr, nullptr, nullptr};
@@ -142,18 +147,24 @@ struct gpis_medium {
     uint64_t prof_launches[3];
 };
 
-static int ensure_stage(gpis_medium *m, int slot, size_t bytes)
+static int ensure_stage(gpis_medium *m, int slot, size_t bytes, bool exact = false)
 {
+    std::lock_guard<std::mutex> lock(m->stage_mu[slot]);
     if (m->stage_bytes[slot] >= bytes)
         return GPIS_OK;
     if (m->stage[slot])
         HIP_TRY(hipFree(m->stage[slot]));
     m->stage[slot] = nullptr;
     m->stage_bytes[slot] = 0;
-    size_t want = bytes + bytes / 4 + 4096;
+    size_t want = exact ? bytes : bytes + bytes / 4 + 4096;     // exact: whole-frame workspaces (tens of GB; allocation time is per byte)
     HIP_TRY(hipMalloc(&m->stage[slot], want));
     m->stage_bytes[slot] = want;
     return GPIS_OK;
+}
+static size_t stage_size(gpis_medium *m, int slot)
+{
+    std::lock_guard<std::mutex> lock(m->stage_mu[slot]);
+    return m->stage_bytes[slot];
 }
 
 // ======================================================================================
@@ -1048,7 +1059,7 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
     if (!m) return set_err(GPIS_ERR_DEVICE, "out of host memory");
     m->params = *params;
     m->device = device;
-    for (int i = 0; i < 5; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
+    for (int i = 0; i < gpis_medium::kStageSlots; ++i) { m->stage[i] = nullptr; m->stage_bytes[i] = 0; }
     m->d_model = nullptr; m->d_counters = nullptr; m->d_guide_cnt = nullptr; m->d_guide = nullptr;
     m->batch_hint = GPIS_ORDER_COHERENT;
     for (int k = 0; k < 2; ++k) { m->ws_event[k] = nullptr; m->ws_event_set[k] = false; }
@@ -1128,7 +1139,7 @@ extern "C" int gpis_destroy(gpis_medium *m)
         if (m->fs_stage[k]) (void)hipFree(m->fs_stage[k]);
     for (int k = 0; k < 3; ++k)
         for (auto &ev : m->events[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < gpis_medium::kStageSlots; ++i)
         if (m->stage[i]) (void)hipFree(m->stage[i]);
     for (int k = 0; k < 2; ++k)
         if (m->ws_event[k]) (void)hipEventDestroy(m->ws_event[k]);
@@ -2015,7 +2026,7 @@ static int chunk_log2(const gpis_medium *m, int default_log2)
 // grows stage[slot] to `bytes` if the device has the memory; false (and no error state) otherwise
 static bool try_stage(gpis_medium *m, int slot, size_t bytes)
 {
-    if (m->stage_bytes[slot] >= bytes)
+    if (stage_size(m, slot) >= bytes)
         return true;
     if (ensure_stage(m, slot, bytes) == GPIS_OK)
         return true;
@@ -2041,6 +2052,54 @@ static SceneConst make_scene_const(const gpis_scene_s *s)
     return sc;
 }
 
+// Workspace of the Lambert driver, 364 B per sample in three allocations: slot 3 [primary rays | shadow jitter | mask], slot 5
+// [segment results], slot 6 [shadow rays | cos | mask | visible | hit].  The chunk is the largest the device can hold, starting from
+// the whole frame (2^27 samples = 48.3 GB).
+struct LambertWs {
+    size_t chunk_pixels, ns_max;
+    size_t b_prim, b_seg, b_shadow;                    // bytes of slots 3, 5, 6
+    size_t o_prim, o_us, o_v1;                         // offsets inside slot 3
+    size_t o_sh, o_cos, o_v2, o_vis, o_hit;            // offsets inside slot 6
+};
+static int lambert_ws_plan(gpis_medium *m, const gpis_scene_s *s, size_t total_pixels, LambertWs &W)
+{
+    for (int l = chunk_log2(m, 27);; --l) {
+        W.chunk_pixels = ((size_t)1 << l) / s->spp_count;
+        if (W.chunk_pixels < 1) W.chunk_pixels = 1;
+        if (W.chunk_pixels > total_pixels) W.chunk_pixels = total_pixels;
+        const size_t n = W.ns_max = W.chunk_pixels * s->spp_count;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        W.o_prim = carve(n * sizeof(gpis_ray_in)); W.o_us = carve(n * 4); W.o_v1 = carve(n);
+        W.b_prim = off;
+        W.b_seg = n * sizeof(gpis_seg_out);
+        off = 0;
+        W.o_sh = carve(n * sizeof(gpis_ray_in)); W.o_cos = carve(n * 4); W.o_v2 = carve(n); W.o_vis = carve(n); W.o_hit = carve(n);
+        W.b_shadow = off;
+        // what is still to be allocated must fit the free memory (with 1 GiB to spare), otherwise halve the chunk
+        const size_t have3 = stage_size(m, 3), have5 = stage_size(m, 5), have6 = stage_size(m, 6);
+        const size_t missing = (have3 >= W.b_prim ? 0 : W.b_prim) + (have5 >= W.b_seg ? 0 : W.b_seg) + (have6 >= W.b_shadow ? 0 : W.b_shadow);
+        if (missing == 0) return GPIS_OK;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t reclaim = (have3 >= W.b_prim ? 0 : have3) + (have5 >= W.b_seg ? 0 : have5) + (have6 >= W.b_shadow ? 0 : have6);   // freed on growth
+        if (missing + ((size_t)1 << 30) <= free_b + reclaim) return GPIS_OK;
+        if (l <= 20) return set_err(GPIS_ERR_DEVICE, "scene driver: no memory for a 1 Mi-sample workspace");
+    }
+}
+
+extern "C" int gpis_reserve_scene_workspace(gpis_medium *m, const gpis_scene_s *s)
+{
+    CHECK_ARGS(m && s);
+    CHECK_ARGS(scene_args_ok(s));
+    HIP_TRY(hipSetDevice(m->device));
+    LambertWs W;
+    if (int rc = lambert_ws_plan(m, s, scene_rows(*s) * s->width, W)) return rc;
+    if (int rc = ensure_stage(m, 3, W.b_prim, true)) return rc;      // in the order the first frame needs them
+    if (int rc = ensure_stage(m, 5, W.b_seg, true)) return rc;
+    return ensure_stage(m, 6, W.b_shadow, true);
+}
+
 extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float *radiance_sum, uint32_t *hit_count, void *stream)
 {
     CHECK_ARGS(m && s && radiance_sum);
@@ -2050,37 +2109,31 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
     hipStream_t st = (hipStream_t)stream;
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = scene_rows(*s) * s->width;
-    // workspace: [prim rays | seg out | shadow rays | u_shadow | cosl | valid | valid2 | vis | hit], ≈375 B per sample;
-    // the largest chunk the device can hold, starting from the whole frame (2^27 samples ≈ 50 GB)
-    size_t chunk_pixels = 0, ns_max = 0, off = 0;
-    size_t o_prim = 0, o_seg = 0, o_sh = 0, o_us = 0, o_cos = 0, o_v1 = 0, o_v2 = 0, o_vis = 0, o_hit = 0;
+    LambertWs W;
+    if (int rc0 = lambert_ws_plan(m, s, total_pixels, W)) return rc0;
     int rc = GPIS_OK;
-    for (int l = chunk_log2(m, 27);; --l) {
-        chunk_pixels = ((size_t)1 << l) / s->spp_count;
-        if (chunk_pixels < 1) chunk_pixels = 1;
-        if (chunk_pixels > total_pixels) chunk_pixels = total_pixels;
-        ns_max = chunk_pixels * s->spp_count;
-        off = 0;
-        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-        o_prim = carve(ns_max * sizeof(gpis_ray_in)); o_seg = carve(ns_max * sizeof(gpis_seg_out)); o_sh = carve(ns_max * sizeof(gpis_ray_in));
-        o_us = carve(ns_max * 4); o_cos = carve(ns_max * 4); o_v1 = carve(ns_max); o_v2 = carve(ns_max); o_vis = carve(ns_max); o_hit = carve(ns_max);
-        if (try_stage(m, 3, off))
-            break;
-        if (l <= 20) return set_err(GPIS_ERR_DEVICE, "scene driver: no memory for a 1 Mi-sample workspace");
-    }
     if ((rc = ws_acquire(m, 0, st))) return rc;
-    char *ws = (char *)m->stage[3];
-    gpis_ray_in *prim = (gpis_ray_in *)(ws + o_prim);
-    gpis_seg_out *seg = (gpis_seg_out *)(ws + o_seg);
-    gpis_ray_in *sh = (gpis_ray_in *)(ws + o_sh);
-    float *us = (float *)(ws + o_us), *cosl = (float *)(ws + o_cos);
-    uint8_t *v1 = (uint8_t *)(ws + o_v1), *v2 = (uint8_t *)(ws + o_v2), *vis = (uint8_t *)(ws + o_vis), *hit = (uint8_t *)(ws + o_hit);
+    // each of the three allocations is made (first frame only) right before the first kernel that needs it, i.e. while the kernels
+    // launched so far run: the 29 GB of segment results and shadow-ray arrays of a whole 1920x1080x64 frame cost no wall time
+    if ((rc = ensure_stage(m, 3, W.b_prim, true))) return rc;
+    char *ws3 = (char *)m->stage[3];
+    gpis_ray_in *prim = (gpis_ray_in *)(ws3 + W.o_prim);
+    float *us = (float *)(ws3 + W.o_us);
+    uint8_t *v1 = (uint8_t *)(ws3 + W.o_v1);
+    const size_t chunk_pixels = W.chunk_pixels;
     for (size_t p0 = 0; p0 < total_pixels; p0 += chunk_pixels) {
         size_t np = total_pixels - p0 < chunk_pixels ? total_pixels - p0 : chunk_pixels;
         size_t ns = np * s->spp_count;
         k_scene_primary<<<grid_of(ns, 256), 256, 0, st>>>(sc, p0, ns, prim, us, v1);
         if ((rc = launch_check("k_scene_primary"))) return rc;
+        if ((rc = ensure_stage(m, 5, W.b_seg, true))) return rc;
+        gpis_seg_out *seg = (gpis_seg_out *)m->stage[5];
         if ((rc = sample_distance_impl(m, ns, prim, seg, nullptr, v1, st))) return rc;
+        if ((rc = ensure_stage(m, 6, W.b_shadow, true))) return rc;
+        char *ws6 = (char *)m->stage[6];
+        gpis_ray_in *sh = (gpis_ray_in *)(ws6 + W.o_sh);
+        float *cosl = (float *)(ws6 + W.o_cos);
+        uint8_t *v2 = (uint8_t *)(ws6 + W.o_v2), *vis = (uint8_t *)(ws6 + W.o_vis), *hit = (uint8_t *)(ws6 + W.o_hit);
         k_scene_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, ns, prim, seg, us, v1, sh, cosl, v2, hit);
         if ((rc = launch_check("k_scene_shade"))) return rc;
         if ((rc = transmittance_impl(m, ns, sh, vis, v2, st))) return rc;
