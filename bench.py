@@ -238,6 +238,7 @@ def main():
                     help="auto: C2 (1D sampling, MIS, conductor) renders through the conductor NEE estimator (gpis_render_scene_s_nee, "
                          "TraceBase.cpp:346-420 / ConductorBsdf.cpp:68-137) as BASELINE.json states it, everything else through scene S's "
                          "Lambert + one shadow ray estimator")
+    ap.add_argument("--reserve-thread", action="store_true", help="cold frame: gpis_reserve_scene_workspace from a second thread during the guide build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unguided", action="store_true", help="skip the extra unguided frame (value_unguided)")
     args = ap.parse_args()
@@ -288,10 +289,11 @@ def main():
     t_created = time.perf_counter()
     lib = med.L.lib
     use_nee = args.estimator == "nee" or (args.estimator == "auto" and args.config == "C2")
-    # the Lambert driver's workspace is reserved from a second host thread while the guide field is built (what a renderer's
-    # set-up does: the two do not depend on each other, and allocation time is per byte)
+    # --reserve-thread: the Lambert driver's workspace is reserved from a second host thread while the guide field is built.
+    # Measured (profiles/r03_cold_frame.md): on never-touched VRAM the 48 GB allocation then stalls the guide build's own
+    # allocations and launches (guide 0.23 -> 1.19 s), so it is off by default; the driver allocates on demand instead.
     reserve = None
-    if not use_nee:
+    if not use_nee and args.reserve_thread:
         import threading
         parts = pkg.dist.shard_scene(scene, rank, world, args.shard)
         reserve_rc = []
