@@ -525,7 +525,7 @@ typedef struct gpis_scene_s {
 
 void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp);
 
-/* Allocates the workspace gpis_render_scene_s needs for `s` (364 B per sample of the largest chunk the device holds: 48.3 GB for
+/* Allocates the workspace gpis_render_scene_s needs for `s` (236 B per sample of the largest chunk the device holds: 31.3 GB for
  * a whole 1920x1080x64 frame) ahead of the first frame.  Optional: the render entry allocates on demand, each of its three arrays
  * right before the first kernel that needs it.  This entry does not take the handle's lock: call it from a second host thread
  * while gpis_build_guide runs (allocation time is per byte and overlaps the guide build's kernels) — not concurrently with a

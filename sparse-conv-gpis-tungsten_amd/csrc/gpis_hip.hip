@@ -504,9 +504,11 @@ __global__ void __launch_bounds__(256) k_scene_primary(SceneConst sc, size_t fir
     valid[i] = hit ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_scene_shade(SceneConst sc, size_t n_samples, const gpis_ray_in *__restrict__ prim,
+// `shadow` may be `prim` itself (the Lambert driver writes each shadow ray over the primary ray it came from: the same thread has
+// read that record by then, and nothing reads the primary rays afterwards) — hence no __restrict__ on the two.
+__global__ void __launch_bounds__(256) k_scene_shade(SceneConst sc, size_t n_samples, const gpis_ray_in *prim,
                                                      const gpis_seg_out *__restrict__ seg, const float *__restrict__ u_shadow,
-                                                     const uint8_t *__restrict__ valid, gpis_ray_in *__restrict__ shadow,
+                                                     const uint8_t *__restrict__ valid, gpis_ray_in *shadow,
                                                      float *__restrict__ cosl, uint8_t *__restrict__ valid2, uint8_t *__restrict__ hit)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2052,14 +2054,14 @@ static SceneConst make_scene_const(const gpis_scene_s *s)
     return sc;
 }
 
-// Workspace of the Lambert driver, 364 B per sample in three allocations: slot 3 [primary rays | shadow jitter | mask], slot 5
-// [segment results], slot 6 [shadow rays | cos | mask | visible | hit].  The chunk is the largest the device can hold, starting from
-// the whole frame (2^27 samples = 48.3 GB).
+// Workspace of the Lambert driver, 236 B per sample in three allocations: slot 3 [primary rays, overwritten in place by the shadow
+// rays | shadow jitter | mask], slot 5 [segment results], slot 6 [cos | mask | visible | hit].  The chunk is the largest the
+// device can hold, starting from the whole frame (2^27 samples = 31.3 GB; 48.3 GB with separate shadow rays until round 3).
 struct LambertWs {
     size_t chunk_pixels, ns_max;
     size_t b_prim, b_seg, b_shadow;                    // bytes of slots 3, 5, 6
     size_t o_prim, o_us, o_v1;                         // offsets inside slot 3
-    size_t o_sh, o_cos, o_v2, o_vis, o_hit;            // offsets inside slot 6
+    size_t o_cos, o_v2, o_vis, o_hit;                  // offsets inside slot 6
 };
 static int lambert_ws_plan(gpis_medium *m, const gpis_scene_s *s, size_t total_pixels, LambertWs &W)
 {
@@ -2074,7 +2076,7 @@ static int lambert_ws_plan(gpis_medium *m, const gpis_scene_s *s, size_t total_p
         W.b_prim = off;
         W.b_seg = n * sizeof(gpis_seg_out);
         off = 0;
-        W.o_sh = carve(n * sizeof(gpis_ray_in)); W.o_cos = carve(n * 4); W.o_v2 = carve(n); W.o_vis = carve(n); W.o_hit = carve(n);
+        W.o_cos = carve(n * 4); W.o_v2 = carve(n); W.o_vis = carve(n); W.o_hit = carve(n);
         W.b_shadow = off;
         // what is still to be allocated must fit the free memory (with 1 GiB to spare), otherwise halve the chunk
         const size_t have3 = stage_size(m, 3), have5 = stage_size(m, 5), have6 = stage_size(m, 6);
@@ -2114,7 +2116,7 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
     int rc = GPIS_OK;
     if ((rc = ws_acquire(m, 0, st))) return rc;
     // each of the three allocations is made (first frame only) right before the first kernel that needs it, i.e. while the kernels
-    // launched so far run: the 29 GB of segment results and shadow-ray arrays of a whole 1920x1080x64 frame cost no wall time
+    // launched so far run
     if ((rc = ensure_stage(m, 3, W.b_prim, true))) return rc;
     char *ws3 = (char *)m->stage[3];
     gpis_ray_in *prim = (gpis_ray_in *)(ws3 + W.o_prim);
@@ -2131,7 +2133,7 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
         if ((rc = sample_distance_impl(m, ns, prim, seg, nullptr, v1, st))) return rc;
         if ((rc = ensure_stage(m, 6, W.b_shadow, true))) return rc;
         char *ws6 = (char *)m->stage[6];
-        gpis_ray_in *sh = (gpis_ray_in *)(ws6 + W.o_sh);
+        gpis_ray_in *sh = prim;
         float *cosl = (float *)(ws6 + W.o_cos);
         uint8_t *v2 = (uint8_t *)(ws6 + W.o_v2), *vis = (uint8_t *)(ws6 + W.o_vis), *hit = (uint8_t *)(ws6 + W.o_hit);
         k_scene_shade<<<grid_of(ns, 256), 256, 0, st>>>(sc, ns, prim, seg, us, v1, sh, cosl, v2, hit);
