@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GPIS_ABI_VERSION 2
+#define GPIS_ABI_VERSION 3
 
 typedef enum gpis_status {
     GPIS_OK = 0,
@@ -186,7 +186,33 @@ typedef struct gpis_params {
     int32_t fs_sample_points;        /* "sample_points" (2 .. GPIS_FS_MAX_POINTS; the reference's default is 32) */
     int32_t _pad3;
     double fs_step_size;             /* "step_size" of the function-space medium (0 = the whole segment in one batch of points) */
+    /* --- GridNonstationaryCovariance (GPF.cpp:1326-1427; needs nonstationary = 1): the variance comes from a voxel grid
+     *     (gpis_set_variance_grid; 1 until one is set, GPF.cpp:1386-1391) and the kernel scale from a threshold on it.  The "ls",
+     *     "var" and "aniso" fields of the procedural wrapper are not read in this flavour. --- */
+    int32_t grid_nonstationary;      /* 1: this flavour of the non-stationary wrapper */
+    int32_t grid_surf_vol_amp_separate; /* "surf_vol_amp_separate" */
+    float grid_offset, grid_scale;   /* "offset", "scale": (density + offset) * scale */
+    float grid_surf_vol_amp_thresh;  /* "surf_vol_amp_thresh" */
+    float grid_surf_amp_scale, grid_vol_amp_scale;   /* "surf_amp_scale", "vol_amp_scale" */
+    float grid_surf_ls_scale, grid_vol_ls_scale;     /* "surf_ls_scale", "vol_ls_scale" */
+    int32_t _pad4;
 } gpis_params;
+
+/* The voxel grid of a GridNonstationaryCovariance, as a dense array: what VdbGrid::density(p) (VdbGrid.cpp:405-431) returns for
+ * an index-space point — p clamped to [bounds_min + 2, bounds_max - 3], then OpenVDB's PointSampler (interpolate 0) or BoxSampler
+ * (1: trilinear, weights in double, each stage narrowed to float).  OpenVDB is not vendored by the reference and absent here: the
+ * two samplers are restated from its published source (tools/Interpolation.h); PARITY UNPINNED for this lookup.  "quadratic" is
+ * refused.  voxel (i, j, k) of the index-space box origin + [0, dims) is voxels[i + dims[0] * (j + dims[1] * k)]; anything
+ * outside it is 0 (the tree's background). */
+typedef struct gpis_variance_grid {
+    int32_t dims[3];
+    int32_t interpolate;             /* 0 "point", 1 "linear" */
+    int32_t origin[3];               /* index-space coordinate of voxel (0, 0, 0) */
+    int32_t _pad;
+    float bounds_min[3], bounds_max[3];   /* VdbGrid::bounds() (index space) */
+    float inv_natural_transform[16]; /* row-major Mat4f, world -> index space (VdbGrid::invNaturalTransform) */
+} gpis_variance_grid;
+/* (set with gpis_set_variance_grid, declared with the other entry points below) */
 
 /* The function-space comparison path (FunctionSpaceGaussianProcessMedium.cpp:58-282): the field is sampled at `sample_points`
  * positions of the segment from the multivariate normal the GP prior (or its conditional, given the previous segment's
@@ -524,6 +550,10 @@ typedef struct gpis_scene_s {
 } gpis_scene_s;
 
 void gpis_default_scene_s(gpis_scene_s *s, uint32_t width, uint32_t height, uint32_t spp);
+
+/* Copies `voxels` (host pointer, dims[0] * dims[1] * dims[2] floats) to the device and switches the lookup on.  The medium must
+ * have been created with grid_nonstationary = 1.  Not to be called while work of this handle is in flight. */
+int gpis_set_variance_grid(gpis_medium *m, const gpis_variance_grid *g, const float *voxels);
 
 /* Allocates the workspace gpis_render_scene_s needs for `s` (236 B per sample of the largest chunk the device holds: 31.3 GB for
  * a whole 1920x1080x64 frame) ahead of the first frame.  Optional: the render entry allocates on demand, each of its three arrays

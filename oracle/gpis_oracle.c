@@ -297,6 +297,9 @@ struct oracle_medium {
     int absorption_only;
     double lin_dir[2][3]; /* LinearMean direction after normalize() */
     int threads;
+    /* GridNonstationaryCovariance: the voxel grid (oracle_set_variance_grid); grid_vox == NULL: getUnscaledVariance = 1 */
+    gpis_variance_grid grid;
+    float *grid_vox;
     oracle_counters counters[ORACLE_MAX_THREADS];
 };
 
@@ -509,11 +512,73 @@ static void ramp_vec_of(const gpis_ramp *r, v3d p, double out[3])
 {
     noise_vec(r->type, r->min, r->max, r->start, r->end, r->min2, r->max2, r->start2, r->end2, p, out);
 }
+/* ---- GridNonstationaryCovariance, GPF.cpp:1386-1427 over VdbGrid::density, VdbGrid.cpp:405-431 ---------------------------
+ * OpenVDB's samplers restated from tools/Interpolation.h (absent dependency: parity unpinned for this lookup):
+ *   PointSampler: the voxel at floor(p + 0.5);
+ *   BoxSampler: the 8 voxels at floor(p) + {0,1}^3, weights uvw = p - floor(p) in double, interpolated along z, then y, then x
+ *   with  lerp(a, b, w) = float(a + float((b - a) * w)). */
+static float grid_voxel(const oracle_medium *m, long i, long j, long k)
+{
+    const gpis_variance_grid *g = &m->grid;
+    i -= g->origin[0]; j -= g->origin[1]; k -= g->origin[2];
+    if (i < 0 || j < 0 || k < 0 || i >= g->dims[0] || j >= g->dims[1] || k >= g->dims[2]) return 0.f;
+    return m->grid_vox[(size_t)i + (size_t)g->dims[0] * ((size_t)j + (size_t)g->dims[1] * (size_t)k)];
+}
+static float grid_lerp(float a, float b, double w) { double temp = (double)(b - a) * w; return a + (float)temp; }
+static float grid_density(const oracle_medium *m, v3f p)
+{
+    const gpis_variance_grid *g = &m->grid;
+    float q[3] = {p.x, p.y, p.z};
+    for (int c = 0; c < 3; ++c) {                                   /* clamp(p, bounds.min + 2, bounds.max - 3): min(max(p, lo), hi) */
+        float lo = g->bounds_min[c] + 2, hi = g->bounds_max[c] - 3;
+        float v = q[c] < lo ? lo : q[c];
+        q[c] = v < hi ? v : hi;
+    }
+    double x = q[0], y = q[1], z = q[2];
+    if (g->interpolate == 0)
+        return grid_voxel(m, (long)floor(x + 0.5), (long)floor(y + 0.5), (long)floor(z + 0.5));
+    double fx = floor(x), fy = floor(y), fz = floor(z);
+    long i = (long)fx, j = (long)fy, k = (long)fz;
+    double u = x - fx, v = y - fy, w = z - fz;
+    float d[2][2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int c = 0; c < 2; ++c) d[a][b][c] = grid_voxel(m, i + a, j + b, k + c);
+    return grid_lerp(grid_lerp(grid_lerp(d[0][0][0], d[0][0][1], w), grid_lerp(d[0][1][0], d[0][1][1], w), v),
+                     grid_lerp(grid_lerp(d[1][0][0], d[1][0][1], w), grid_lerp(d[1][1][0], d[1][1][1], w), v), u);
+}
+/* getUnscaledVariance, GPF.cpp:1386-1391: (density(invNaturalTransform * Vec3f(p)) + offset) * scale; Mat4f * Vec3f as Mat4f.hpp:329-336 */
+static float grid_unscaled_variance(const oracle_medium *m, v3d pd)
+{
+    if (!m->grid_vox) return 1.f;
+    const float *T = m->grid.inv_natural_transform;
+    float x = (float)pd.x, y = (float)pd.y, z = (float)pd.z;
+    v3f q = v3(T[0] * x + T[1] * y + T[2] * z + T[3], T[4] * x + T[5] * y + T[6] * z + T[7], T[8] * x + T[9] * y + T[10] * z + T[11]);
+    return (grid_density(m, q) + m->P.grid_offset) * m->P.grid_scale;
+}
+/* getVariance, GPF.cpp:1393-1403 */
+static double grid_variance(const oracle_medium *m, v3d p)
+{
+    float amplitude = grid_unscaled_variance(m, p);
+    if (!m->P.grid_surf_vol_amp_separate) return amplitude;
+    if (amplitude < m->P.grid_surf_vol_amp_thresh) return amplitude * m->P.grid_surf_amp_scale;
+    return amplitude * m->P.grid_vol_amp_scale;
+}
+/* getKernelScale, GPF.cpp:1409-1420 */
+static float grid_kernel_scale(const oracle_medium *m, v3f p)
+{
+    if (m->P.grid_surf_vol_amp_separate) {
+        float amplitude = grid_unscaled_variance(m, v3d_of(p));
+        return amplitude < m->P.grid_surf_vol_amp_thresh ? m->P.grid_surf_ls_scale : m->P.grid_vol_ls_scale;
+    }
+    return 1.f;
+}
+
 /* sparseConvNoiseLateralScale: GPF.cpp:607-609 / 1219-1221 → getKernelScale GPF.cpp:1729-1735 */
 static float cov_lateral_scale(const oracle_medium *m, v3f p)
 {
     if (!m->P.nonstationary)
         return 1.0f;
+    if (m->P.grid_nonstationary)
+        return grid_kernel_scale(m, p);
     const gpis_params *P = &m->P;
     double ls[3];
     noise_vec(P->ls_ramp_type, P->ls_min, P->ls_max, P->ls_start, P->ls_end, P->ls_min2, P->ls_max2, P->ls_start2, P->ls_end2, v3d_of(p), ls);
@@ -538,6 +603,8 @@ static float cov_amplitude(const oracle_medium *m, v3f p)
 {
     if (!m->P.nonstationary)
         return m->P.sigma;
+    if (m->P.grid_nonstationary)
+        return (float)(grid_variance(m, v3d_of(p)) * m->P.sigma);
     double var = m->P.var.enabled ? ramp_of(&m->P.var, v3d_of(p)) : 1.0;
     return (float)(var * m->P.sigma);
 }
@@ -1300,8 +1367,9 @@ static float evaluate_value(realization *r, v3f p, float t, v3f rayDir, ray_info
     mean_weight_space(m, v3d_of(p), &mean, &id);
     *GPId = (int)id;
     if (m->P.surf_vol_phase_separate) {
-        /* getUnscaledVariance = 1 for the kernels in scope (GPF.hpp:1185) */
-        if (1.f < m->P.surf_vol_phase_amp_thresh) *GPId = 0; else *GPId = 1;
+        /* getUnscaledVariance = 1 (GPF.hpp:1185) except in the grid flavour (GPF.cpp:1386-1391) */
+        float uv = m->P.grid_nonstationary ? grid_unscaled_variance(m, v3d_of(p)) : 1.f;
+        if (uv < m->P.surf_vol_phase_amp_thresh) *GPId = 0; else *GPId = 1;
     }
     return (float)(amplitude * noise_val + mean);
 }
@@ -1887,6 +1955,8 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
         if (!params->nonstationary) return fail("an aniso field needs the proc_nonstationary wrapper");
         if (params->sampling_1d) return fail("an aniso field is built for 3D sampling only");
     }
+    if (params->grid_nonstationary && (!params->nonstationary || params->var.enabled || params->aniso_field.enabled))
+        return fail("the grid flavour needs nonstationary = 1 and carries no var / aniso field");
     if (params->kernel_type < 0 || params->kernel_type > 3) return fail("invalid kernel type");
     if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
         if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 1.5f && params->matern_v != 2.5f)
@@ -1948,6 +2018,8 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
         if (P->ls_ramp_type == GPIS_NOISE_SANDSTONE || P->ls_ramp_type == GPIS_NOISE_RUST)
             mx = 1.;                                         /* GPF.cpp:130-137 */
         m->ls_maxval = (float)mx;
+        if (P->grid_nonstationary)                               /* sparseConvNoiseMaxLateralScale, GPF.cpp:1422-1427 */
+            m->ls_maxval = P->grid_surf_vol_amp_separate ? (P->grid_surf_ls_scale < P->grid_vol_ls_scale ? P->grid_vol_ls_scale : P->grid_surf_ls_scale) : 1.f;
     }
     /* prepareForRender, GPM.cpp:152-158 */
     int all_zero = 1;
@@ -1969,7 +2041,26 @@ int oracle_create(const gpis_params *params, oracle_medium **out)
     *out = m;
     return GPIS_OK;
 }
-void oracle_destroy(oracle_medium *m) { free(m); }
+void oracle_destroy(oracle_medium *m) { if (m) free(m->grid_vox); free(m); }
+/* test export: getUnscaledVariance at n world points (doubles) */
+void oracle_grid_unscaled_variance(const oracle_medium *m, size_t n, const double *p3, float *out)
+{
+    for (size_t i = 0; i < n; ++i) { v3d p = {p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]}; out[i] = grid_unscaled_variance(m, p); }
+}
+int oracle_set_variance_grid(oracle_medium *m, const gpis_variance_grid *g, const float *voxels)
+{
+    if (!m || !g || !voxels) return fail("null argument");
+    if (!m->P.grid_nonstationary) return fail("the medium was not created with grid_nonstationary = 1");
+    if (g->dims[0] < 1 || g->dims[1] < 1 || g->dims[2] < 1 || g->interpolate < 0 || g->interpolate > 1) return fail("invalid grid");
+    size_t n = (size_t)g->dims[0] * (size_t)g->dims[1] * (size_t)g->dims[2];
+    float *v = (float *)malloc(n * sizeof(float));
+    if (!v) return GPIS_ERR_DEVICE;
+    memcpy(v, voxels, n * sizeof(float));
+    free(m->grid_vox);
+    m->grid_vox = v;
+    m->grid = *g;
+    return GPIS_OK;
+}
 void oracle_set_threads(oracle_medium *m, int n) { m->threads = n < 1 ? 1 : (n > ORACLE_MAX_THREADS ? ORACLE_MAX_THREADS : n); }
 
 int oracle_get_derived(const oracle_medium *m, gpis_derived *o)

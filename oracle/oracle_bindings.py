@@ -45,6 +45,7 @@ class Oracle:
         L.oracle_create.argtypes = [_vp, ctypes.POINTER(_vp)]
         L.oracle_destroy.argtypes = [_vp]
         L.oracle_set_threads.argtypes = [_vp, _i32]
+        L.oracle_set_variance_grid.argtypes = [_vp, _vp, _vp]
         L.oracle_get_derived.argtypes = [_vp, _vp]
         L.oracle_sample_distance_batch.argtypes = [_vp, _sz, _vp, _vp, _vp]
         L.oracle_transmittance_batch.argtypes = [_vp, _sz, _vp, _vp]
@@ -75,6 +76,19 @@ class Oracle:
                 self.h = None
         except Exception:
             pass
+
+    def set_variance_grid(self, voxels, world_to_index, interpolate="linear", origin=(0, 0, 0)):
+        d, v = _T.variance_grid_desc(voxels, world_to_index, interpolate, origin)
+        st = self.lib.oracle_set_variance_grid(self.h, d.ctypes.data_as(_vp), v.ctypes.data_as(_vp))
+        if st != 0:
+            raise ValueError("oracle_set_variance_grid failed (%d)" % st)
+
+    def grid_unscaled_variance(self, points):
+        p = np.ascontiguousarray(points, dtype=np.float64)
+        out = np.empty(len(p), dtype=np.float32)
+        self.lib.oracle_grid_unscaled_variance.argtypes = [_vp, _sz, _vp, _vp]
+        self.lib.oracle_grid_unscaled_variance(self.h, len(p), p.ctypes.data_as(_vp), out.ctypes.data_as(_vp))
+        return out
 
     def set_threads(self, n):
         self.lib.oracle_set_threads(self.h, int(n))

@@ -51,7 +51,29 @@ PARAMS = np.dtype([
     ("kernel_type", "<i4"), ("matern_v", "<f4"), ("gabor_a_inv", "<f4"), ("gabor_f_inv", "<f4"), ("gabor_omega", "<f4", 3), ("_pad2", "<i4"),
     ("aniso_field", RAMP),
     ("fs_sample_points", "<i4"), ("_pad3", "<i4"), ("fs_step_size", "<f8"),
+    ("grid_nonstationary", "<i4"), ("grid_surf_vol_amp_separate", "<i4"), ("grid_offset", "<f4"), ("grid_scale", "<f4"),
+    ("grid_surf_vol_amp_thresh", "<f4"), ("grid_surf_amp_scale", "<f4"), ("grid_vol_amp_scale", "<f4"),
+    ("grid_surf_ls_scale", "<f4"), ("grid_vol_ls_scale", "<f4"), ("_pad4", "<i4"),
 ], align=True)
+
+VARIANCE_GRID = np.dtype([
+    ("dims", "<i4", 3), ("interpolate", "<i4"), ("origin", "<i4", 3), ("_pad", "<i4"),
+    ("bounds_min", "<f4", 3), ("bounds_max", "<f4", 3), ("inv_natural_transform", "<f4", 16),
+], align=True)
+
+
+def variance_grid_desc(voxels, world_to_index, interpolate="linear", origin=(0, 0, 0)):
+    """gpis_variance_grid for a dense array voxels[k, j, i] (z, y, x — x fastest in memory) whose voxel (0, 0, 0) sits at the
+    index-space coordinate `origin`; bounds = the whole array, as VdbGrid::bounds() is the box of the active voxels."""
+    v = np.ascontiguousarray(voxels, dtype=np.float32)
+    d = np.zeros((), dtype=VARIANCE_GRID)
+    d["dims"] = (v.shape[2], v.shape[1], v.shape[0])
+    d["interpolate"] = {"point": 0, "linear": 1}[interpolate]
+    d["origin"] = origin
+    d["bounds_min"] = origin
+    d["bounds_max"] = (origin[0] + v.shape[2] - 1, origin[1] + v.shape[1] - 1, origin[2] + v.shape[0] - 1)
+    d["inv_natural_transform"] = np.asarray(world_to_index, dtype=np.float32).reshape(16)
+    return d, v
 
 FS_MAX_POINTS, FS_MAX_CTX = 64, 66
 FS_STATE = np.dtype([
@@ -149,7 +171,9 @@ assert QUERY.itemsize == 96 and NEE_QUERY.itemsize == 96
 def default_params():
     """Reference defaults (SCNM.cpp:17-34, GPM.cpp:86-95, GPF.hpp:1729,1784) as a PARAMS record."""
     p = np.zeros((), dtype=PARAMS)
-    p["abi_version"] = 2
+    p["abi_version"] = 3
+    p["grid_scale"], p["grid_surf_vol_amp_thresh"] = 1.0, 1.0                       # GPF.hpp:2327-2335
+    p["grid_surf_amp_scale"], p["grid_vol_amp_scale"], p["grid_surf_ls_scale"], p["grid_vol_ls_scale"] = 1.0, 1.0, 1.0, 1.0
     p["matern_v"], p["gabor_a_inv"], p["gabor_f_inv"], p["gabor_omega"] = 0.5, 1.0, 1.0, (1.0, 0.0, 0.0)
     p["fs_sample_points"], p["fs_step_size"] = 32, 0.0
     p["step_size"] = 0.01
@@ -278,7 +302,7 @@ class GpisLib:
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
         "gpis_get_counters", "gpis_reset_counters", "gpis_set_profiling", "gpis_get_kernel_profile",
         "gpis_set_batch_order", "gpis_set_option", "gpis_get_option", "gpis_build_guide", "gpis_drop_guide", "gpis_get_guide_info", "gpis_get_guide_steps", "gpis_guide_selfcheck", "gpis_guide_raycheck",
-        "gpis_default_scene_s", "gpis_reserve_scene_workspace", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
+        "gpis_set_variance_grid", "gpis_default_scene_s", "gpis_reserve_scene_workspace", "gpis_render_scene_s", "gpis_render_scene_s_paths", "gpis_render_scene_s_nee",
     ]
 
     def __init__(self, path=None):
@@ -345,6 +369,7 @@ class GpisLib:
         L.gpis_guide_raycheck.argtypes = [vp, sz, vp, u32, vp, vp, vp]
         L.gpis_default_scene_s.argtypes = [vp, u32, u32, u32]
         L.gpis_reserve_scene_workspace.argtypes = [vp, vp]
+        L.gpis_set_variance_grid.argtypes = [vp, vp, vp]
         L.gpis_default_scene_s.restype = None
         L.gpis_render_scene_s.argtypes = [vp, vp, vp, vp, vp]
         L.gpis_render_scene_s_paths.argtypes = [vp, vp, i32, ctypes.c_float, vp, vp]
@@ -535,6 +560,11 @@ class Medium:
 
     def reset_counters(self):
         self.L.check(self.L.lib.gpis_reset_counters(self.h), "gpis_reset_counters")
+
+    def set_variance_grid(self, voxels, world_to_index, interpolate="linear", origin=(0, 0, 0)):
+        """GridNonstationaryCovariance: the voxel grid the variance is read from (voxels[k, j, i], world_to_index = a 4x4 matrix)"""
+        d, v = variance_grid_desc(voxels, world_to_index, interpolate, origin)
+        self.L.check(self.L.lib.gpis_set_variance_grid(self.h, d.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)), "gpis_set_variance_grid")
 
     def build_guide(self, half_extent_cells=16, points_per_cell=32):
         self.L.check(self.L.lib.gpis_build_guide(self.h, int(half_extent_cells), int(points_per_cell)), "gpis_build_guide")

@@ -50,12 +50,25 @@ GPIS_DEV double ramp_unit(double coord, double scale, double offset, double la, 
     double l = la * (1.0 - u) + lb * u;
     return sqrt(exp_glibc(l));
 }
+// GridNonstationaryCovariance's voxel grid (gpis_set_variance_grid); vox == nullptr: getUnscaledVariance = 1
+struct DevGrid {
+    const float *vox;
+    int32_t on;                  // the medium is of the grid flavour
+    int32_t interpolate;
+    int32_t dims[3], origin[3];
+    float lo[3], hi[3];          // bounds_min + 2, bounds_max - 3
+    float T[12];                 // rows 0..2 of invNaturalTransform
+    float offset, scale, thresh, surf_amp, vol_amp, surf_ls, vol_ls;
+    int32_t separate;
+};
 struct DevModel {
     // flags (SCNM.cpp:57-73, SCN.cpp:21-30)
     int32_t single_realization, iso3d, sampling_1d, correlation_xy, ctx;
     int32_t activate_conditioning, scheme_1d_eff, multi_res, nonstationary, multi_resolution_grid;
     int32_t use_aniso_mtx, surf_vol_phase_separate, has_mean_additional, absorption_only, max_bounces;
-    int32_t fbm_noise;            // some procedural field is a sandstone / rust noise: only the all-features path instance evaluates those
+    int32_t fbm_noise;            // some procedural field is a sandstone / rust noise, or the wrapper is of the grid flavour: only the
+                                  // all-features path instance evaluates those
+    DevGrid grid;
     float surf_vol_phase_amp_thresh;
     uint32_t seed, n_impulses, min_step;
     float step_size, impulse_density, sigma;
@@ -341,6 +354,51 @@ GPIS_DEV void field_vec(const DevRamp &R, V3d p, bool fbm_possible, double out[3
         return;
     }
     out[0] = out[1] = out[2] = ramp_eval(R, p);
+}
+// ---- GridNonstationaryCovariance, GPF.cpp:1386-1427 over VdbGrid::density, VdbGrid.cpp:405-431 (OpenVDB's PointSampler / BoxSampler
+// restated from tools/Interpolation.h — absent dependency, parity unpinned for the lookup; same code as the oracle's).  Cold code of
+// the all-features path instance: not inlined.
+static __device__ __attribute__((noinline)) float grid_unscaled_variance(const DevGrid &G, double pxd, double pyd, double pzd)
+{
+    if (!G.vox) return 1.f;
+    const float x = (float)pxd, y = (float)pyd, z = (float)pzd;
+    float q[3] = {G.T[0] * x + G.T[1] * y + G.T[2] * z + G.T[3], G.T[4] * x + G.T[5] * y + G.T[6] * z + G.T[7], G.T[8] * x + G.T[9] * y + G.T[10] * z + G.T[11]};
+    for (int c = 0; c < 3; ++c) {
+        const float v = q[c] < G.lo[c] ? G.lo[c] : q[c];
+        q[c] = v < G.hi[c] ? v : G.hi[c];
+    }
+    auto voxel = [&](long i, long j, long k) -> float {
+        i -= G.origin[0]; j -= G.origin[1]; k -= G.origin[2];
+        if (i < 0 || j < 0 || k < 0 || i >= G.dims[0] || j >= G.dims[1] || k >= G.dims[2]) return 0.f;
+        return G.vox[(size_t)i + (size_t)G.dims[0] * ((size_t)j + (size_t)G.dims[1] * (size_t)k)];
+    };
+    auto lerp = [](float a, float b, double w) -> float { const double temp = (double)(b - a) * w; return a + (float)temp; };
+    const double xd = q[0], yd = q[1], zd = q[2];
+    float dens;
+    if (G.interpolate == 0) {
+        dens = voxel((long)floor(xd + 0.5), (long)floor(yd + 0.5), (long)floor(zd + 0.5));
+    } else {
+        const double fx = floor(xd), fy = floor(yd), fz = floor(zd);
+        const long i = (long)fx, j = (long)fy, k = (long)fz;
+        const double u = xd - fx, v = yd - fy, w = zd - fz;
+        dens = lerp(lerp(lerp(voxel(i, j, k), voxel(i, j, k + 1), w), lerp(voxel(i, j + 1, k), voxel(i, j + 1, k + 1), w), v),
+                    lerp(lerp(voxel(i + 1, j, k), voxel(i + 1, j, k + 1), w), lerp(voxel(i + 1, j + 1, k), voxel(i + 1, j + 1, k + 1), w), v), u);
+    }
+    return (dens + G.offset) * G.scale;
+}
+// getVariance, GPF.cpp:1393-1403
+static __device__ __attribute__((noinline)) double grid_variance(const DevGrid &G, double px, double py, double pz)
+{
+    const float amplitude = grid_unscaled_variance(G, px, py, pz);
+    if (!G.separate) return (double)amplitude;
+    return (double)(amplitude < G.thresh ? amplitude * G.surf_amp : amplitude * G.vol_amp);
+}
+// getKernelScale, GPF.cpp:1409-1420
+static __device__ __attribute__((noinline)) float grid_kernel_scale(const DevGrid &G, float px, float py, float pz)
+{
+    if (!G.separate) return 1.f;
+    const float amplitude = grid_unscaled_variance(G, (double)px, (double)py, (double)pz);
+    return amplitude < G.thresh ? G.surf_ls : G.vol_ls;
 }
 // Modified Bessel functions of the second kind K0(x), K1(x), x > 0, for the Matern v = 3/2 splatting kernel (GPF.cpp:1053-1056,
 // 1071-1074 call boost::math::cyl_bessel_k, which is neither vendored nor installed: PARITY UNPINNED VS BOOST; the same code as

@@ -104,6 +104,7 @@ struct gpis_medium {
     unsigned long long *d_guide_cnt;
     uint64_t selfcheck_tabulated = 0;   // points of the last gpis_guide_selfcheck that fell into tabulated bricks
     GuideField *d_guide;     // device copy of `guide` (the resident guided kernels read it through scalar loads instead of 14 kernel-argument SGPRs)
+    float *d_grid_vox = nullptr;      // GridNonstationaryCovariance voxels (gpis_set_variance_grid)
     void *fs_ws = nullptr;            // function-space workspace: one FsGlob per resident workgroup (gpis_fs.hpp)
     unsigned fs_ws_blocks = 0;
     // staging for the *_host entries and workspace for the renderer (grown on demand)
@@ -297,6 +298,21 @@ static int build_model(const gpis_params &P, DevModel &M, gpis_derived &D)
         M.fbm_noise = 0;
         for (const DevRamp *f : fields)
             if (f->enabled && f->type >= GPIS_NOISE_SANDSTONE) M.fbm_noise = 1;
+    }
+    {   // GridNonstationaryCovariance (GPF.cpp:1326-1427): variance and kernel scale from a voxel grid (gpis_set_variance_grid)
+        memset(&M.grid, 0, sizeof M.grid);
+        M.grid.on = P.grid_nonstationary != 0;
+        M.grid.offset = P.grid_offset; M.grid.scale = P.grid_scale;
+        M.grid.separate = P.grid_surf_vol_amp_separate != 0;
+        M.grid.thresh = P.grid_surf_vol_amp_thresh;
+        M.grid.surf_amp = P.grid_surf_amp_scale; M.grid.vol_amp = P.grid_vol_amp_scale;
+        M.grid.surf_ls = P.grid_surf_ls_scale; M.grid.vol_ls = P.grid_vol_ls_scale;
+        if (M.grid.on) {
+            M.fbm_noise = 1;                                     // all-features path instance
+            M.ls.enabled = 0;
+            // sparseConvNoiseMaxLateralScale, GPF.cpp:1422-1427
+            M.ls_maxval = M.grid.separate ? (P.grid_surf_ls_scale < P.grid_vol_ls_scale ? P.grid_vol_ls_scale : P.grid_surf_ls_scale) : 1.f;
+        }
     }
     const float base = 2.5f;
     M.log_base = logf(base);
@@ -1011,6 +1027,8 @@ extern "C" void gpis_default_params(gpis_params *p)
     p->ls_min2 = 1.; p->ls_max2 = 500.; p->ls_start2 = 0.; p->ls_end2 = 1.;          // GPF.hpp:694-699
     p->matern_v = 0.5f; p->gabor_a_inv = 1.f; p->gabor_f_inv = 1.f; p->gabor_omega[0] = 1.f;   // GPF.hpp:1964, 2041, 2079
     p->fs_sample_points = 32; p->fs_step_size = 0.;                                  // FunctionSpace...cpp:24-26
+    p->grid_scale = 1.f; p->grid_surf_vol_amp_thresh = 1.f;                          // GPF.hpp:2327-2335
+    p->grid_surf_amp_scale = p->grid_vol_amp_scale = p->grid_surf_ls_scale = p->grid_vol_ls_scale = 1.f;
     gpis_ramp *ramps[4] = {&p->var, &p->mean_color, &p->mean_emission, &p->aniso_field};
     for (gpis_ramp *r : ramps) { r->min = 1.; r->max = 500.; r->start = 0.; r->end = 1.; r->min2 = 1.; r->max2 = 500.; r->start2 = 0.; r->end2 = 1.; }
     p->mean.type = GPIS_MEAN_SPHERICAL; p->mean.radius = 1.f;
@@ -1040,6 +1058,8 @@ extern "C" int gpis_create(const gpis_params *params, int device, gpis_medium **
             if (params->sampling_1d) return set_err(GPIS_ERR_INVALID_ARG, "an \"aniso\" field is built for 3D sampling only (GPF.cpp:1691-1727 are outside the built scope)");
         }
     }
+    if (params->grid_nonstationary && (!params->nonstationary || params->var.enabled || params->aniso_field.enabled))
+        return set_err(GPIS_ERR_INVALID_ARG, "the grid flavour of the non-stationary wrapper needs nonstationary = 1 and carries no var / aniso field");
     if (params->kernel_type < 0 || params->kernel_type > 3) return set_err(GPIS_ERR_INVALID_ARG, "invalid kernel type");
     if (params->kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL) {
         if (params->kernel_type == GPIS_KERNEL_MATERN && params->matern_v != 0.5f && params->matern_v != 1.5f && params->matern_v != 2.5f)
@@ -1137,6 +1157,7 @@ extern "C" int gpis_destroy(gpis_medium *m)
     if (m->d_guide_cnt) (void)hipFree(m->d_guide_cnt);
     if (m->d_guide) (void)hipFree(m->d_guide);
     if (m->fs_ws) (void)hipFree(m->fs_ws);
+    if (m->d_grid_vox) (void)hipFree(m->d_grid_vox);
     for (int k = 0; k < 3; ++k)
         if (m->fs_stage[k]) (void)hipFree(m->fs_stage[k]);
     for (int k = 0; k < 3; ++k)
@@ -2088,6 +2109,29 @@ static int lambert_ws_plan(gpis_medium *m, const gpis_scene_s *s, size_t total_p
         if (missing + ((size_t)1 << 30) <= free_b + reclaim) return GPIS_OK;
         if (l <= 20) return set_err(GPIS_ERR_DEVICE, "scene driver: no memory for a 1 Mi-sample workspace");
     }
+}
+
+extern "C" int gpis_set_variance_grid(gpis_medium *m, const gpis_variance_grid *g, const float *voxels)
+{
+    CHECK_ARGS(m && g && voxels);
+    CHECK_ARGS(g->dims[0] >= 1 && g->dims[1] >= 1 && g->dims[2] >= 1 && (g->interpolate == 0 || g->interpolate == 1));
+    if (!m->host_model.grid.on) return set_err(GPIS_ERR_INVALID_ARG, "gpis_set_variance_grid: the medium was not created with grid_nonstationary = 1");
+    std::lock_guard<std::mutex> lock(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = (size_t)g->dims[0] * (size_t)g->dims[1] * (size_t)g->dims[2];
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(&d, n * sizeof(float)));
+    if (hipMemcpy(d, voxels, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return set_err(GPIS_ERR_DEVICE, "gpis_set_variance_grid: copy failed"); }
+    if (m->d_grid_vox) HIP_TRY(hipFree(m->d_grid_vox));
+    m->d_grid_vox = d;
+    DevGrid &G = m->host_model.grid;
+    G.vox = d;
+    G.interpolate = g->interpolate;
+    for (int c = 0; c < 3; ++c) { G.dims[c] = g->dims[c]; G.origin[c] = g->origin[c]; G.lo[c] = g->bounds_min[c] + 2; G.hi[c] = g->bounds_max[c] - 3; }
+    for (int i = 0; i < 12; ++i) G.T[i] = g->inv_natural_transform[i];
+    HIP_TRY(hipMemcpy(m->d_model, &m->host_model, sizeof(DevModel), hipMemcpyHostToDevice));
+    return GPIS_OK;
 }
 
 extern "C" int gpis_reserve_scene_workspace(gpis_medium *m, const gpis_scene_s *s)

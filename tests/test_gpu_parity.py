@@ -615,6 +615,41 @@ def test_variance_field_btlr_color_emission(env, multires):
     assert not np.array_equal(pkg.Medium(plain).eval_value(q)[0], med.eval_value(q)[0])
 
 
+@pytest.mark.parametrize("multires,iso,interpolate,separate", [(1, 1, "linear", 1), (0, 0, "linear", 1), (0, 1, "point", 0), (1, 0, "linear", 0)])
+def test_grid_nonstationary_covariance(env, multires, iso, interpolate, separate):
+    """SURVEY.md f3: GridNonstationaryCovariance (GPF.cpp:1326-1427) — variance from a voxel grid through VdbGrid::density
+    (clamp, OpenVDB Point / Box sampler: restated, parity unpinned for the lookup, tests/test_grid_oracle_cpu.py), kernel scale
+    and amplitude scale from the surface / volume threshold, phase id from the same unscaled variance (SCN.cpp:81-86).
+    Device against the CPU restatement, bit for bit."""
+    pkg, ob, lib = env
+    import test_grid_oracle_cpu as G
+    params = G._params(pkg, separate)
+    params["multi_resolution_grid"], params["isotropic_3d_sampling"] = multires, iso
+    params["correlation_context"] = pkg.CTX.RENEWAL
+    params["surf_vol_phase_separate"], params["surf_vol_phase_amp_thresh"] = 1, 1.4
+    vox, T = G._grid(24, seed=9), G._world_to_index(24)
+    med, orc = pkg.Medium(params), ob.Oracle(params, threads=16)
+    q = _queries(pkg, 1024, 91)
+    assert np.array_equal(med.eval_value(q)[0], orc.eval_value(q)[0])            # no grid yet: variance 1
+    med.set_variance_grid(vox, T, interpolate)
+    orc.set_variance_grid(vox, T, interpolate)
+    d_g, d_o = med.derived(), orc.derived()
+    assert d_g["kernel_radius_world"] == d_o["kernel_radius_world"] and d_g["kernel_radius_iso"] == d_o["kernel_radius_iso"]
+    (vg, ig), (vo, io) = med.eval_value(q), orc.eval_value(q)
+    assert np.array_equal(vg, vo) and np.array_equal(ig, io) and (io == 0).any() and (io == 1).any()
+    assert np.array_equal(med.eval_gradient(q), orc.eval_gradient(q), equal_nan=True)
+    scene = ob.default_scene_s(96, 54, 1)
+    rays, us = scene_rays(ob, orc, scene, step=3)
+    got, want = med.sample_distance(rays), orc.sample_distance(rays)
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+    assert (want["exited"] == 0).sum() > 20
+    sh = shadow_rays_from(ob, scene, rays, us, want)
+    assert np.array_equal(med.transmittance(sh), orc.transmittance(sh))
+    with pytest.raises(RuntimeError):
+        pkg.Medium(pkg.params_for_config("C3")).set_variance_grid(vox, T)          # not of the grid flavour
+
+
 @pytest.mark.parametrize("noise", ["sandstone", "rust"])
 def test_sandstone_and_rust_noises(env, noise):
     """SURVEY.md a23: NoiseType::Sandstone / Rust of ProceduralNoise (scalar fields "var", "aniso": 2 fbm octaves, lerp(min, max, .))
