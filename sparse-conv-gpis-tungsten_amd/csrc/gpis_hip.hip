@@ -105,6 +105,7 @@ struct gpis_medium {
     uint64_t selfcheck_tabulated = 0;   // points of the last gpis_guide_selfcheck that fell into tabulated bricks
     GuideField *d_guide;     // device copy of `guide` (the resident guided kernels read it through scalar loads instead of 14 kernel-argument SGPRs)
     float *d_grid_vox = nullptr;      // GridNonstationaryCovariance voxels (gpis_set_variance_grid)
+    unsigned lambert_calls = 0;       // gpis_render_scene_s calls so far (the first one works in small chunks, see lambert_ws_plan)
     void *fs_ws = nullptr;            // function-space workspace: one FsGlob per resident workgroup (gpis_fs.hpp)
     unsigned fs_ws_blocks = 0;
     // staging for the *_host entries and workspace for the renderer (grown on demand)
@@ -2084,9 +2085,20 @@ struct LambertWs {
     size_t o_prim, o_us, o_v1;                         // offsets inside slot 3
     size_t o_cos, o_v2, o_vis, o_hit;                  // offsets inside slot 6
 };
-static int lambert_ws_plan(gpis_medium *m, const gpis_scene_s *s, size_t total_pixels, LambertWs &W)
+// First-use policy: memory this process allocates for the first time costs 15-30 ms per GB on these boxes (DESIGN.md §6 "cold
+// frame"), so the whole-frame workspace (31 GB) would triple the latency of a handle's FIRST frame.  That frame therefore runs in
+// 16 Mi-sample chunks (4 GB, -4 % throughput); from the second call on — the handle is evidently reused — the workspace grows to
+// the whole frame.  A workspace that is already large enough (gpis_reserve_scene_workspace, an earlier larger call) is used as is,
+// and GPIS_CHUNK_LOG2 / GPIS_OPT_CHUNK_LOG2 override the policy.
+static int lambert_ws_plan(gpis_medium *m, const gpis_scene_s *s, size_t total_pixels, LambertWs &W, bool first_call = false)
 {
-    for (int l = chunk_log2(m, 27);; --l) {
+    int l0 = chunk_log2(m, 27);
+    if (first_call && !m->opt[GPIS_OPT_CHUNK_LOG2]) {
+        const size_t whole = (total_pixels * s->spp_count < ((size_t)1 << 27) ? total_pixels * s->spp_count : ((size_t)1 << 27));
+        const bool have_whole = stage_size(m, 3) >= whole * (sizeof(gpis_ray_in) + 5) && stage_size(m, 5) >= whole * sizeof(gpis_seg_out) && stage_size(m, 6) >= whole * 7;
+        if (!have_whole) l0 = 24;
+    }
+    for (int l = l0;; --l) {
         W.chunk_pixels = ((size_t)1 << l) / s->spp_count;
         if (W.chunk_pixels < 1) W.chunk_pixels = 1;
         if (W.chunk_pixels > total_pixels) W.chunk_pixels = total_pixels;
@@ -2156,7 +2168,8 @@ extern "C" int gpis_render_scene_s(gpis_medium *m, const gpis_scene_s *s, float 
     SceneConst sc = make_scene_const(s);
     const size_t total_pixels = scene_rows(*s) * s->width;
     LambertWs W;
-    if (int rc0 = lambert_ws_plan(m, s, total_pixels, W)) return rc0;
+    if (int rc0 = lambert_ws_plan(m, s, total_pixels, W, m->lambert_calls == 0)) return rc0;
+    ++m->lambert_calls;
     int rc = GPIS_OK;
     if ((rc = ws_acquire(m, 0, st))) return rc;
     // each of the three allocations is made (first frame only) right before the first kernel that needs it, i.e. while the kernels
