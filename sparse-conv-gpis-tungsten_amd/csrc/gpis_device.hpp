@@ -757,6 +757,7 @@ struct PersistQueue {
     uint64_t exptab[32];                           // glibc's exp2f table (expf_glibc_lds)
     uint32_t e0[Q][64], e1[Q][64], e2[Q][64];      // (x | w sign, y, z) of the impulses that passed the unit-ball test, slot-major
     uint32_t ready[128];                           // ring of unmasked ray indices waiting for a free lane (refill, gpis_persist.inc)
+    uint32_t rq[4];                                // the ring's head, count, "batch exhausted" flag: kept here, not in (S)GPRs across the march
 };
 enum PersistPhase : int {
     PP_IDLE = 0,      // no ray (batch drained)
