@@ -1361,6 +1361,7 @@ static int launch_persist(gpis_medium *m, PersistArgs a, hipStream_t s)
         int nb = launch::persist_blocks_per_cu(inst, WANT_SAMPLE);
         if (nb <= 0) nb = 8;
         m->persist_waves[slot_id] = nb * m->n_cus;
+        if (getenv("GPIS_DEBUG")) fprintf(stderr, "gpis: persistent march instance %d (%s): %d resident waves per CU x %d CUs\n", inst, WANT_SAMPLE ? "sampleDistance" : "transmittance", nb, m->n_cus);
     }
     const size_t waves_needed = (a.n + kBlock - 1) / kBlock;
     const unsigned grid = (unsigned)(waves_needed < (size_t)m->persist_waves[slot_id] ? waves_needed : (size_t)m->persist_waves[slot_id]);
