@@ -424,6 +424,11 @@ typedef enum gpis_libm_fn { GPIS_LIBM_EXP = 0, GPIS_LIBM_LOG = 1, GPIS_LIBM_LOGF
                             GPIS_LIBM_POW = 6, GPIS_LIBM_SINCOSF = 7 } gpis_libm_fn;
 int gpis_libm_batch(int fn, size_t n, const double *x, const double *y, double *out, double *out2, void *stream);
 
+/* Test surface of the library's own radix sort (csrc/gpis_sort.hip: stable LSD sort of (uint32 key, uint32 value) pairs, used by
+ * the wavefront march and the multi-bounce driver to regroup rays by lattice cell).  Device pointers; scratch is allocated and
+ * freed inside the call. */
+int gpis_sort_pairs_u32(size_t n, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, void *stream);
+
 /* Bit-exact primitives (MathUtil.hpp:179-224, UniformSampler.hpp:41-75, BitManip.hpp:47-50):
  * out[i] = xxhash32 of `arity` (1..4) words at words[i*arity..]; and the PCG32 stream
  * after set_state(state[i]) — `count` raw nextI() draws each. */

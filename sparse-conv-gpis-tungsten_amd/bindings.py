@@ -296,7 +296,7 @@ class GpisLib:
         "gpis_sample_distance_batch", "gpis_transmittance_batch", "gpis_eval_value_batch",
         "gpis_eval_gradient_batch", "gpis_conditioning_batch", "gpis_nee_pdf_batch", "gpis_nee_grad_batch",
         "gpis_xxhash32_batch", "gpis_pcg32_stream_batch", "gpis_mean_color_emission_batch", "gpis_mean_color_emission_host",
-        "gpis_fs_sample_distance_batch", "gpis_fs_transmittance_batch", "gpis_fs_linalg_batch", "gpis_libm_batch",
+        "gpis_fs_sample_distance_batch", "gpis_fs_transmittance_batch", "gpis_fs_linalg_batch", "gpis_libm_batch", "gpis_sort_pairs_u32",
         "gpis_fs_sample_distance_host", "gpis_fs_transmittance_host",
         "gpis_sample_distance_host", "gpis_transmittance_host", "gpis_eval_value_host", "gpis_eval_gradient_host",
         "gpis_conditioning_host", "gpis_nee_pdf_host", "gpis_nee_grad_host", "gpis_alloc_host", "gpis_free_host",
@@ -339,6 +339,7 @@ class GpisLib:
         L.gpis_mean_color_emission_batch.argtypes = [vp, sz, vp, vp, vp, vp]
         L.gpis_fs_linalg_batch.argtypes = [vp, i32, i32, sz, vp, vp, vp, vp]
         L.gpis_libm_batch.argtypes = [i32, sz, vp, vp, vp, vp, vp]
+        L.gpis_sort_pairs_u32.argtypes = [sz, vp, vp, vp, vp, vp]
         L.gpis_fs_sample_distance_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_fs_transmittance_host.argtypes = [vp, sz, vp, vp, vp]
         L.gpis_mean_color_emission_host.argtypes = [vp, sz, vp, vp, vp]
@@ -417,6 +418,22 @@ def libm_eval(fn, x, y=None, device=0, lib=None):
                                   ctypes.c_void_p(d_o.data_ptr()), ctypes.c_void_p(d_o2.data_ptr()), None), "gpis_libm_batch")
     torch.cuda.synchronize(dev)
     return (d_o.cpu().numpy(), d_o2.cpu().numpy()) if fn in ("sincos", "sincosf") else d_o.cpu().numpy()
+
+
+def sort_pairs_u32(keys, vals, device=0, lib=None):
+    """Test surface: the library's radix sort on arrays of uint32 keys / values; returns (keys_sorted, vals_sorted)."""
+    import torch
+    L = lib or load_library()
+    dev = torch.device("cuda", device)
+    torch.cuda.set_device(dev)
+    k = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.uint32).view(np.int32)).to(dev)
+    v = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.uint32).view(np.int32)).to(dev)
+    ko, vo = torch.zeros_like(k), torch.zeros_like(v)
+    torch.cuda.synchronize(dev)
+    L.check(L.lib.gpis_sort_pairs_u32(k.numel(), ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(ko.data_ptr()),
+                                      ctypes.c_void_p(vo.data_ptr()), None), "gpis_sort_pairs_u32")
+    torch.cuda.synchronize(dev)
+    return ko.cpu().numpy().view(np.uint32), vo.cpu().numpy().view(np.uint32)
 
 
 class Medium:

@@ -1587,6 +1587,21 @@ extern "C" int gpis_fs_linalg_batch(gpis_medium *m, int op, int n, size_t count,
     launch::fs_linalg((unsigned)(count < cap ? count : cap), op, n, count, in, out, evals, m->fs_ws, (hipStream_t)stream);
     return launch_check("k_fs_linalg");
 }
+extern "C" int gpis_sort_pairs_u32(size_t n, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, void *stream)
+{
+    CHECK_ARGS(n == 0 || (keys_in && vals_in && keys_out && vals_out));
+    size_t tb = 0;
+    if (sort_pairs_u32(nullptr, tb, nullptr, nullptr, nullptr, nullptr, n, (hipStream_t)stream) != hipSuccess)
+        return set_err(GPIS_ERR_INVALID_ARG, "gpis_sort_pairs_u32: batch too large");
+    if (n == 0) return GPIS_OK;
+    void *temp = nullptr;
+    HIP_TRY(hipMalloc(&temp, tb));
+    hipError_t e = sort_pairs_u32(temp, tb, keys_in, keys_out, vals_in, vals_out, n, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(temp);
+    if (e != hipSuccess) return set_err(GPIS_ERR_DEVICE, "gpis_sort_pairs_u32: %s", hipGetErrorString(e));
+    return GPIS_OK;
+}
 extern "C" int gpis_libm_batch(int fn, size_t n, const double *x, const double *y, double *out, double *out2, void *stream)
 {
     CHECK_ARGS(fn >= GPIS_LIBM_EXP && fn <= GPIS_LIBM_SINCOSF && (n == 0 || (x && out)) && (fn != GPIS_LIBM_POW || n == 0 || y) && ((fn != GPIS_LIBM_SINCOS && fn != GPIS_LIBM_SINCOSF) || n == 0 || out2));
