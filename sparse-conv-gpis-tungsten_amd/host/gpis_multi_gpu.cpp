@@ -183,7 +183,7 @@ int run_rank(const Options &o, int rank, int world, const ncclUniqueId &id)
         printf("{\"metric\": \"Msamples/s (primary rays x spp / s)\", \"value\": %.6f, \"unit\": \"Msamples/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, "
                "\"ms_per_step\": %.3f, \"higher_is_better\": true, \"scaling\": \"strong\", \"vs_baseline\": null, \"dtype\": \"f32\", \"data\": \"synthetic\", "
                "\"config\": {\"workload\": \"%s: scene S %dx%d, %d spp\", \"sharding\": \"16-pixel tile rows round-robin, one batch per rank, one gather of "
-               "disjoint rows (RCCL send/recv group)\", \"guide\": %s, \"driver\": \"host/gpis_multi_gpu.cpp\"}, \"radiance_sum\": %.9g, \"wire_bytes_per_frame\": %zu, \"per_rank\": [",
+               "disjoint rows (RCCL send/recv group)\", \"guide\": %s, \"driver\": \"host/gpis_multi_gpu.cpp\"}, \"radiance_sum\": %.17g, \"wire_bytes_per_frame\": %zu, \"per_rank\": [",
                samples / dt / 1e6, world, o.steps, o.warmup, dt / o.steps * 1e3, o.config.c_str(), o.width, o.height, o.spp,
                guided ? "true" : "false", sum, wire_bytes);
         for (int r = 0; r < world; ++r)

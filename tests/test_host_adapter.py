@@ -64,4 +64,4 @@ def test_multi_gpu_driver_single_rank_frame_equals_the_python_driver(pkg):
     rad = torch.zeros(480 * 270, dtype=torch.float32, device="cuda")
     med.call("gpis_render_scene_s", scene.ctypes.data_as(ctypes.c_void_p), rad.data_ptr(), None, None)
     torch.cuda.synchronize()
-    assert float(rad.cpu().numpy().astype(np.float64).sum()) == pytest.approx(line["radiance_sum"], rel=1e-12)
+    assert float(rad.cpu().numpy().astype(np.float64).sum()) == pytest.approx(line["radiance_sum"], rel=1e-10)      # the same pixels, summed in another order
