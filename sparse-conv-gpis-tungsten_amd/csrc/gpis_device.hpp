@@ -756,7 +756,12 @@ template <int Q>
 struct PersistQueue {
     uint64_t exptab[32];                           // glibc's exp2f table (expf_glibc_lds)
     uint32_t e0[Q][64], e1[Q][64], e2[Q][64];      // (x | w sign, y, z) of the impulses that passed the unit-ball test, slot-major
-    uint32_t ready[128];                           // ring of unmasked ray indices waiting for a free lane (refill, gpis_persist.inc)
+    // ring of unmasked ray indices waiting for a free lane (refill, gpis_persist.inc).  56 entries, not 128: LDS is handed out in
+    // 1280-byte granules on this chip, 12 one-wave workgroups per CU leave 12 800 B each, and the queues above take 12 544 — with a
+    // 128-entry ring (13 072 B) only 11 workgroups fit although the occupancy query still says 12, and every persistent launch
+    // lost 5-8 % (C3 480x270x8 sampleDistance 631 -> 670 ms) whichever refill scheme it ran.
+    static constexpr int kReady = 56;
+    uint32_t ready[kReady];
     uint32_t rq[4];                                // the ring's head, count, "batch exhausted" flag: kept here, not in (S)GPRs across the march
 };
 enum PersistPhase : int {
