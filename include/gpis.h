@@ -24,6 +24,12 @@
  * mutex while they ENQUEUE (kernels of different callers still overlap on the device); the
  * workspaces the handle owns (tile drivers, wavefront march) are handed from one caller's stream
  * to the next with an event, so a second caller never overwrites a workspace still in use.
+ * The `*_host` entries are the exception: they hold the mutex END TO END (upload, kernel, event
+ * wait, download) because the two staging slots are state of the handle — concurrent batch-of-one
+ * callers of one handle (Tungsten's render workers through the Medium adapter) are served one
+ * after the other, 150 us each.  That path is a compatibility path, not a throughput path:
+ * a renderer that wants the GPU busy batches its rays.  The function-space
+ * host entries serialise the same way on their own lock.
  * gpis_destroy / gpis_build_guide / gpis_drop_guide must not race with other calls on the handle.
  *
  * Environment: a few diagnostic overrides are read ONCE, in gpis_create, as the initial values
