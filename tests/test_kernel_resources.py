@@ -57,6 +57,8 @@ def test_hot_kernels_keep_their_budget(pkg):
     for sub, scratch in (("7spec_3d7PersistE", 0), ("16spec_3d_multires7PersistE", 64), ("7spec_1d7PersistE", 160)):
         for v in one("k_persist_marchINS_" + sub):
             assert v["vgpr_count"] <= 168 and v["private_segment_fixed_size"] <= scratch, (sub, v)   # 3 waves/SIMD
-            assert v["group_segment_fixed_size"] <= 16 * 1024
+            # LDS comes in 1280-byte granules: 12 one-wave workgroups per CU (3 per SIMD) leave 10 granules each.  13 072 B once
+            # cost every persistent launch 5-8 % while the occupancy query still said 12 ("refill").
+            assert v["group_segment_fixed_size"] <= 12800, (sub, v)
     for v in one("k_fs_marchILb"):                        # four workgroups per CU (one per SIMD), no scratch
         assert v["group_segment_fixed_size"] <= 40 * 1024 and v["private_segment_fixed_size"] == 0, v
