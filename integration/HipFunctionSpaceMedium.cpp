@@ -1,6 +1,7 @@
 // HipFunctionSpaceMedium.cpp — see the header.  Compiles against the reference's real headers with the same command as
 // HipSparseConvNoiseMedium.cpp (tests/test_integration_compile.py).  Links against libgpis_hip.so.
 #include "HipFunctionSpaceMedium.hpp"
+#include "TungstenJsonAccess.hpp"
 
 #include "io/JsonObject.hpp"
 #include "sampling/UniformSampler.hpp"
@@ -12,20 +13,6 @@ namespace Tungsten {
 
 GPContextHipFs::GPContextHipFs() { std::memset(&st, 0, sizeof st); }
 void GPContextHipFs::reset() { std::memset(&st, 0, sizeof st); }
-
-// GaussianProcessMedium::stringToCorrelationContext, GaussianProcessMedium.cpp:30-41
-static int fsCorrelationContext(const std::string &name)
-{
-    if (name == "global")
-        return GPIS_CTX_GLOBAL;
-    else if (name == "renewal+")
-        return GPIS_CTX_RENEWAL_PLUS;
-    else if (name == "renewal")
-        return GPIS_CTX_RENEWAL;
-    else if (name == "none")
-        return GPIS_CTX_NONE;
-    FAIL("Invalid correlation context: '%s'", name);
-}
 
 HipFunctionSpaceMedium::HipFunctionSpaceMedium()
 : _handle(nullptr),
@@ -51,57 +38,21 @@ void HipFunctionSpaceMedium::fromJson(JsonPtr value, const Scene &scene)
     Medium::fromJson(value, scene);      // phase_function, transmittance, max_bounces (Medium.cpp:29-38)
     _params.max_bounces = _maxBounce;
 
-    // GaussianProcessMedium::fromJson, GaussianProcessMedium.cpp:97-126
-    Vec3f sa(_params.sigma_a[0], _params.sigma_a[1], _params.sigma_a[2]);
-    Vec3f ss(_params.sigma_s[0], _params.sigma_s[1], _params.sigma_s[2]);
-    value.getField("sigma_a", sa);
-    value.getField("sigma_s", ss);
-    for (int i = 0; i < 3; ++i) { _params.sigma_a[i] = sa[i]; _params.sigma_s[i] = ss[i]; }
-    value.getField("density", _params.density);
+    // GaussianProcessMedium::fromJson (GaussianProcessMedium.cpp:97-126) and GaussianProcess::fromJson for an inline object
+    // (GaussianProcess.cpp:172-190) through the shared key table (include/gpis_json.hpp); the device path of this medium is built
+    // for an analytic mean and a stationary squared-exponential covariance (include/gpis.h "function-space comparison path")
+    TungstenJson::vec3f(value, "sigma_a", _params.sigma_a);
+    TungstenJson::vec3f(value, "sigma_s", _params.sigma_s);
+    TungstenJson::num(value, "density", _params.density);
     std::string ctxtString = "goldfish";
     value.getField("correlation_context", ctxtString);
-    _params.correlation_context = fsCorrelationContext(ctxtString);
+    _params.correlation_context = gpis_json::correlationContext<TungstenJson>(ctxtString);
     if (auto gp = value["gaussian_process"]) {
-        // GaussianProcess::fromJson (GaussianProcess.cpp:172-190), inline object: analytic mean + squared exponential
-        // (the device path is built for those, include/gpis.h "function-space comparison path")
         if (!gp.isObject())
             FAIL("hip_function_space_gaussian_process: \"gaussian_process\" must be an inline object");
-        if (auto m = gp["mean"]) {
-            std::string type = "spherical";
-            m.getField("type", type);
-            gpis_mean &dst = _params.mean;
-            if (type == "homogeneous") {
-                dst.type = GPIS_MEAN_HOMOGENEOUS;
-                m.getField("offset", dst.offset);
-            } else if (type == "spherical") {
-                dst.type = GPIS_MEAN_SPHERICAL;
-                Vec3d c(dst.center[0], dst.center[1], dst.center[2]);
-                m.getField("center", c);
-                for (int i = 0; i < 3; ++i) dst.center[i] = c[i];
-                m.getField("radius", dst.radius);
-            } else if (type == "linear") {
-                dst.type = GPIS_MEAN_LINEAR;
-                Vec3d r(dst.center[0], dst.center[1], dst.center[2]), d(dst.dir[0], dst.dir[1], dst.dir[2]);
-                m.getField("reference_point", r);
-                m.getField("direction", d);
-                for (int i = 0; i < 3; ++i) { dst.center[i] = r[i]; dst.dir[i] = d[i]; }
-                m.getField("scale", dst.scale);
-                m.getField("min", dst.min);
-            } else {
-                FAIL("hip_function_space_gaussian_process: unsupported mean function type: '%s'", type);
-            }
-        }
-        if (auto c = gp["covariance"]) {
-            std::string type = "squared_exponential";
-            c.getField("type", type);
-            if (type != "squared_exponential")
-                FAIL("hip_function_space_gaussian_process: unsupported covariance type: '%s'", type);
-            c.getField("sigma", _params.sigma);                        // SquaredExponentialCovariance::fromJson, GPFunctions.cpp:654-679
-            c.getField("lengthScale", _params.length_scale);
-            Vec3f aniso(_params.aniso[0], _params.aniso[1], _params.aniso[2]);
-            c.getField("aniso", aniso);
-            for (int i = 0; i < 3; ++i) _params.aniso[i] = aniso[i];
-        }
+        gpis_json::readGaussianProcess<TungstenJson>(gp, _params);
+        if (_params.nonstationary || _params.kernel_type != GPIS_KERNEL_SQUARED_EXPONENTIAL || _params.has_mean_additional)
+            FAIL("hip_function_space_gaussian_process: built for one analytic mean and a stationary squared-exponential covariance");
     }
     _phaseFunctions.clear();
     _phaseFunctions.push_back(_phaseFunction);

@@ -5,35 +5,15 @@
 #include "HipSparseConvNoiseMedium.hpp"
 
 #include "io/JsonObject.hpp"
+#include "TungstenJsonAccess.hpp"
 
 #include <cmath>
 #include <cstring>
 
 namespace Tungsten {
 
-int HipSparseConvNoiseMedium::stringToCorrelationContext(const std::string &name)
-{
-    if (name == "global")
-        return GPIS_CTX_GLOBAL;
-    else if (name == "renewal+")
-        return GPIS_CTX_RENEWAL_PLUS;
-    else if (name == "renewal")
-        return GPIS_CTX_RENEWAL;
-    else if (name == "none")
-        return GPIS_CTX_NONE;
-    FAIL("Invalid correlation context: '%s'", name);
-}
-
-int HipSparseConvNoiseMedium::stringToSamplingScheme1D(const std::string &name)
-{
-    if (name == "uni" || name == "UNI")
-        return GPIS_UNI;
-    else if (name == "nee" || name == "NEE")
-        return GPIS_NEE;
-    else if (name == "mis" || name == "MIS")
-        return GPIS_MIS;
-    FAIL("Invalid sparse conv sampling scheme: '%s'", name);
-}
+int HipSparseConvNoiseMedium::stringToCorrelationContext(const std::string &name) { return gpis_json::correlationContext<TungstenJson>(name); }
+int HipSparseConvNoiseMedium::stringToSamplingScheme1D(const std::string &name) { return gpis_json::samplingScheme1D<TungstenJson>(name); }
 
 HipSparseConvNoiseMedium::HipSparseConvNoiseMedium()
 : _handle(nullptr),
@@ -51,182 +31,22 @@ HipSparseConvNoiseMedium::~HipSparseConvNoiseMedium()
     teardownAfterRender();
 }
 
-// MeanFunction subclasses, GPFunctions.hpp:867-1005
-void HipSparseConvNoiseMedium::readMean(JsonPtr m, gpis_mean &dst)
-{
-    std::string type = "spherical";
-    m.getField("type", type);
-    if (type == "homogeneous") {
-        dst.type = GPIS_MEAN_HOMOGENEOUS;
-        m.getField("offset", dst.offset);
-    } else if (type == "spherical") {
-        dst.type = GPIS_MEAN_SPHERICAL;
-        Vec3d c(dst.center[0], dst.center[1], dst.center[2]);
-        m.getField("center", c);
-        for (int i = 0; i < 3; ++i) dst.center[i] = c[i];
-        m.getField("radius", dst.radius);
-    } else if (type == "linear") {
-        dst.type = GPIS_MEAN_LINEAR;
-        Vec3d r(dst.center[0], dst.center[1], dst.center[2]), d(dst.dir[0], dst.dir[1], dst.dir[2]);
-        m.getField("reference_point", r);
-        m.getField("direction", d);
-        for (int i = 0; i < 3; ++i) { dst.center[i] = r[i]; dst.dir[i] = d[i]; }
-        m.getField("scale", dst.scale);
-        m.getField("min", dst.min);
-    } else {
-        FAIL("hip_sparse_conv_noise: unsupported mean function type: '%s'", type);
-    }
-}
-
-// ProceduralNoise / ProceduralNoiseVec::fromJson, GPFunctions.hpp:671-688 / 752-769
-static int noiseType(const std::string &noise)
-{
-    if (noise == "bottom_top") return GPIS_RAMP_BOTTOM_TOP;
-    if (noise == "left_right") return GPIS_RAMP_LEFT_RIGHT;
-    if (noise == "front_back") return GPIS_RAMP_FRONT_BACK;
-    if (noise == "bottom_top_left_right") return GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT;
-    FAIL("hip_sparse_conv_noise: unsupported noise type: '%s'", noise);
-}
-static void readRamp(JsonPtr v, gpis_ramp &r)
-{
-    r.enabled = 1;
-    std::string noise = "bottom_top";
-    v.getField("noise", noise);
-    r.type = noiseType(noise);
-    v.getField("min", r.min); v.getField("max", r.max); v.getField("start", r.start); v.getField("end", r.end);
-    v.getField("min2", r.min2); v.getField("max2", r.max2); v.getField("start2", r.start2); v.getField("end2", r.end2);
-}
-
-// SquaredExponentialCovariance::fromJson, GPFunctions.cpp:654-679; "localScale" GPFunctions.hpp:1481-1484
-void HipSparseConvNoiseMedium::readSquaredExponential(JsonPtr c)
-{
-    c.getField("sigma", _params.sigma);
-    c.getField("lengthScale", _params.length_scale);
-    Vec3f aniso(_params.aniso[0], _params.aniso[1], _params.aniso[2]);
-    c.getField("aniso", aniso);
-    for (int i = 0; i < 3; ++i) _params.aniso[i] = aniso[i];
-    bool useMtx = _params.use_aniso_mtx != 0;
-    c.getField("useAnisoMtx", useMtx);
-    _params.use_aniso_mtx = useMtx ? 1 : 0;
-    if (auto mtx = c["anisoMtx"]) {
-        Eigen::Matrix3f a;
-        mtx.get(a);
-        for (int r = 0; r < 3; ++r)
-            for (int col = 0; col < 3; ++col)
-                _params.aniso_mtx[3*r + col] = a(r, col);
-    }
-    c.getField("localScale", _params.local_scale);
-}
-
-// GaussianProcess::fromJson (GaussianProcess.cpp:172-190) for an inline object.  The reference resolves
-// "gaussian_process" through Scene::fetchGaussianProcess, which also accepts the NAME of a process declared
-// at scene level; a maintainer who wants that form adds accessors to GaussianProcess and fills _params from
-// them here (GaussianProcess.hpp keeps _mean/_cov public).
-void HipSparseConvNoiseMedium::readGaussianProcess(JsonPtr gp)
-{
-    if (!gp.isObject())
-        FAIL("hip_sparse_conv_noise: \"gaussian_process\" must be an inline object");
-    if (auto m = gp["mean"]) {
-        readMean(m, _params.mean);
-        if (auto c = m["color"]) readRamp(c, _params.mean_color);          // MeanFunction::fromJson, GPFunctions.hpp:808-818
-        if (auto e = m["emission"]) readRamp(e, _params.mean_emission);
-    }
-    if (auto m = gp["mean_additional"]) {   // GPSampleNodeCSG's second mean (GaussianProcess.cpp:25-39)
-        _params.has_mean_additional = 1;
-        readMean(m, _params.mean_additional);
-    }
-    if (auto c = gp["covariance"]) {
-        std::string type = "squared_exponential";
-        c.getField("type", type);
-        if (type == "squared_exponential") {
-            readSquaredExponential(c);
-        } else if (type == "matern") {                     // MaternCovariance::fromJson, GPFunctions.cpp:866-876
-            _params.kernel_type = GPIS_KERNEL_MATERN;
-            c.getField("sigma", _params.sigma);
-            c.getField("v", _params.matern_v);
-            c.getField("lengthScale", _params.length_scale);
-            Vec3f aniso(_params.aniso[0], _params.aniso[1], _params.aniso[2]);
-            c.getField("aniso", aniso);
-            for (int i = 0; i < 3; ++i) _params.aniso[i] = aniso[i];
-            c.getField("localScale", _params.local_scale);
-        } else if (type == "gabor_aniso" || type == "gabor_iso") {     // GPFunctions.cpp:1086-1096, 1155-1162
-            _params.kernel_type = type == "gabor_aniso" ? GPIS_KERNEL_GABOR_ANISO : GPIS_KERNEL_GABOR_ISO;
-            c.getField("sigma", _params.sigma);
-            c.getField("a_inv", _params.gabor_a_inv);
-            c.getField("f_inv", _params.gabor_f_inv);
-            Vec3f omega(_params.gabor_omega[0], _params.gabor_omega[1], _params.gabor_omega[2]);
-            c.getField("omega", omega);
-            for (int i = 0; i < 3; ++i) _params.gabor_omega[i] = omega[i];
-            c.getField("localScale", _params.local_scale);
-        } else if (type == "proc_nonstationary") {      // GPFunctions.cpp:1590-1606, GPFunctions.hpp:2211-2217
-            _params.nonstationary = 1;
-            bool grid = _params.multi_resolution_grid != 0;
-            c.getField("multiResolutionGrid", grid);
-            _params.multi_resolution_grid = grid ? 1 : 0;
-            if (auto inner = c["cov"])
-                readSquaredExponential(inner);
-            if (auto ls = c["ls"]) {                    // ProceduralNoiseVec, GPFunctions.hpp:759-776
-                std::string noise = "bottom_top";
-                ls.getField("noise", noise);
-                _params.ls_ramp_type = noiseType(noise);
-                ls.getField("min", _params.ls_min);
-                ls.getField("max", _params.ls_max);
-                ls.getField("start", _params.ls_start);
-                ls.getField("end", _params.ls_end);
-                ls.getField("min2", _params.ls_min2);
-                ls.getField("max2", _params.ls_max2);
-                ls.getField("start2", _params.ls_start2);
-                ls.getField("end2", _params.ls_end2);
-            }
-            if (auto var = c["var"])                     // GPFunctions.cpp:1593-1595
-                readRamp(var, _params.var);
-            if (auto an = c["aniso"])                    // GPFunctions.cpp:1600-1602
-                readRamp(an, _params.aniso_field);
-        } else {
-            FAIL("hip_sparse_conv_noise: unsupported covariance type: '%s'", type);
-        }
-    }
-}
-
 void HipSparseConvNoiseMedium::fromJson(JsonPtr value, const Scene &scene)
 {
     Medium::fromJson(value, scene);      // phase_function, transmittance, max_bounces (Medium.cpp:29-38)
     _params.max_bounces = _maxBounce;
 
-    // GaussianProcessMedium::fromJson, GaussianProcessMedium.cpp:97-126
-    Vec3f sa(_params.sigma_a[0], _params.sigma_a[1], _params.sigma_a[2]);
-    Vec3f ss(_params.sigma_s[0], _params.sigma_s[1], _params.sigma_s[2]);
-    value.getField("sigma_a", sa);
-    value.getField("sigma_s", ss);
-    for (int i = 0; i < 3; ++i) { _params.sigma_a[i] = sa[i]; _params.sigma_s[i] = ss[i]; }
-    value.getField("density", _params.density);
-    std::string ctxtString = "goldfish";
-    value.getField("correlation_context", ctxtString);
-    _params.correlation_context = stringToCorrelationContext(ctxtString);
+    // GaussianProcessMedium::fromJson (GaussianProcessMedium.cpp:97-126), GaussianProcess::fromJson for an INLINE object
+    // (GaussianProcess.cpp:172-190) and SparseConvolutionNoiseMedium::fromJson (SparseConvolutionNoiseMedium.cpp:57-73): the key
+    // table of include/gpis_json.hpp.  The reference resolves "gaussian_process" through Scene::fetchGaussianProcess, which also
+    // accepts the NAME of a process declared at scene level; a maintainer who wants that form adds accessors to GaussianProcess
+    // and fills _params from them here (GaussianProcess.hpp keeps _mean / _cov public).
     if (auto gp = value["gaussian_process"])
-        readGaussianProcess(gp);
+        if (!gp.isObject())
+            FAIL("hip_sparse_conv_noise: \"gaussian_process\" must be an inline object");
+    gpis_json::readMedium<TungstenJson>(value, _params);
     _phaseFunctions.clear();
     _phaseFunctions.push_back(_phaseFunction);     // "We always have the default one"
-
-    // SparseConvolutionNoiseMedium::fromJson, SparseConvolutionNoiseMedium.cpp:57-73
-    value.getField("step_size", _params.step_size);
-    value.getField("min_step", _params.min_step);
-    value.getField("seed", _params.seed);
-    value.getField("impulse_density", _params.impulse_density);
-    auto flag = [&](const char *key, int32_t &dst) {
-        bool b = dst != 0;
-        value.getField(key, b);
-        dst = b ? 1 : 0;
-    };
-    flag("single_realization", _params.single_realization);
-    flag("isotropic_3D_sampling", _params.isotropic_3d_sampling);
-    flag("1D_sampling", _params.sampling_1d);
-    std::string scheme1DString = "uni";
-    value.getField("1D_sampling_scheme", scheme1DString);
-    _params.scheme_1d = stringToSamplingScheme1D(scheme1DString);
-    flag("1D_gradient_correlationXY", _params.correlation_xy);
-    flag("surf_vol_phase_separate", _params.surf_vol_phase_separate);
-    value.getField("surf_vol_phase_amp_thresh", _params.surf_vol_phase_amp_thresh);
     int device = _device;
     value.getField("hip_device", device);
     _device = device;

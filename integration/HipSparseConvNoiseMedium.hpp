@@ -50,9 +50,6 @@ class HipSparseConvNoiseMedium : public Medium
 
     static int stringToCorrelationContext(const std::string &name);   // GaussianProcessMedium.cpp:30-41
     static int stringToSamplingScheme1D(const std::string &name);     // SparseConvolutionNoiseMedium.cpp:36-45
-    void readMean(JsonPtr m, gpis_mean &dst);
-    void readSquaredExponential(JsonPtr c);
-    void readGaussianProcess(JsonPtr gp);
     void fillRay(const Ray &ray, const MediumState &state, float u, gpis_ray_in &r) const;
 
 public:

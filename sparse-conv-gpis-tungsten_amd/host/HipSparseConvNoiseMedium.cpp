@@ -1,5 +1,6 @@
 // HipSparseConvNoiseMedium.cpp — see the header.  Plain C++17 (g++), links libgpis_hip.so.
 #include "HipSparseConvNoiseMedium.hpp"
+#include "gpis_json.hpp"
 
 #include <cctype>
 #include <cmath>
@@ -96,103 +97,58 @@ struct JParser {
     }
 };
 
-template <typename T>
-void getNum(const JValue &o, const char *key, T &dst)
-{
-    if (const JValue *v = o.get(key)) {
-        if (v->kind == JValue::Number) dst = (T)v->num;
-        else if (v->kind == JValue::Bool) dst = (T)(v->b ? 1 : 0);
+// accessor of include/gpis_json.hpp over this file's parser (the integration adapter has the same over Tungsten's JsonPtr)
+struct HostJson {
+    using Node = const JValue *;
+    static bool child(const Node &o, const char *key, Node &out)
+    {
+        const JValue *v = o->get(key);
+        if (!v) return false;
+        out = v;
+        return true;
     }
-}
-// Vec3f fields accept a scalar or a 3-array, as Tungsten's JsonPtr does for Vec3f
-void getVec3(const JValue &o, const char *key, float *dst)
-{
-    if (const JValue *v = o.get(key)) {
-        if (v->kind == JValue::Number) dst[0] = dst[1] = dst[2] = (float)v->num;
-        else if (v->kind == JValue::Array && v->arr.size() == 3)
-            for (int i = 0; i < 3; ++i) dst[i] = (float)v->arr[i].num;
+    template <typename T> static void num(const Node &o, const char *key, T &dst)
+    {
+        if (const JValue *v = o->get(key)) {
+            if (v->kind == JValue::Number) dst = (T)v->num;
+            else if (v->kind == JValue::Bool) dst = (T)(v->b ? 1 : 0);
+        }
     }
-}
-void getVec3d(const JValue &o, const char *key, double *dst)
-{
-    if (const JValue *v = o.get(key)) {
-        if (v->kind == JValue::Number) dst[0] = dst[1] = dst[2] = v->num;
-        else if (v->kind == JValue::Array && v->arr.size() == 3)
-            for (int i = 0; i < 3; ++i) dst[i] = v->arr[i].num;
+    static void flag(const Node &o, const char *key, int32_t &dst) { num(o, key, dst); }
+    static void str(const Node &o, const char *key, std::string &dst)
+    {
+        if (const JValue *v = o->get(key)) dst = v->str;
     }
-}
-
-int noiseType(const std::string &noise)            // ProceduralNoise(Vec)::stringToNoiseType, GPF.hpp:644-661
-{
-    if (noise == "bottom_top") return GPIS_RAMP_BOTTOM_TOP;
-    if (noise == "left_right") return GPIS_RAMP_LEFT_RIGHT;
-    if (noise == "front_back") return GPIS_RAMP_FRONT_BACK;
-    if (noise == "bottom_top_left_right") return GPIS_RAMP_BOTTOM_TOP_LEFT_RIGHT;
-    if (noise == "sandstone" || noise == "rust") throw std::runtime_error("noise type '" + noise + "' is outside the built scope");
-    throw std::runtime_error("Invalid noise typ function: '" + noise + "'");
-}
-void readRamp(const JValue &v, gpis_ramp &r)         // ProceduralNoise::fromJson, GPF.hpp:671-688
-{
-    r.enabled = 1;
-    std::string noise = "bottom_top";
-    if (const JValue *n = v.get("noise")) noise = n->str;
-    r.type = noiseType(noise);
-    getNum(v, "min", r.min); getNum(v, "max", r.max); getNum(v, "start", r.start); getNum(v, "end", r.end);
-    getNum(v, "min2", r.min2); getNum(v, "max2", r.max2); getNum(v, "start2", r.start2); getNum(v, "end2", r.end2);
-}
-
-void readMean(const JValue &m, gpis_mean &dst)
-{
-    std::string type = "spherical";
-    if (const JValue *t = m.get("type")) type = t->str;
-    if (type == "homogeneous") {                     // GPF.hpp:871-874
-        dst.type = GPIS_MEAN_HOMOGENEOUS;
-        getNum(m, "offset", dst.offset);
-    } else if (type == "spherical") {                // GPF.hpp:908-912
-        dst.type = GPIS_MEAN_SPHERICAL;
-        getVec3d(m, "center", dst.center);
-        getNum(m, "radius", dst.radius);
-    } else if (type == "linear") {                   // GPF.hpp:953-962
-        dst.type = GPIS_MEAN_LINEAR;
-        getVec3d(m, "reference_point", dst.center);
-        getVec3d(m, "direction", dst.dir);
-        getNum(m, "scale", dst.scale);
-        getNum(m, "min", dst.min);
-    } else {
-        throw std::runtime_error("Unsupported mean function type: '" + type + "'");
+    // Vec3f fields accept a scalar or a 3-array, as Tungsten's JsonPtr does for Vec3f
+    template <typename T> static void vec3(const Node &o, const char *key, T *dst)
+    {
+        if (const JValue *v = o->get(key)) {
+            if (v->kind == JValue::Number) dst[0] = dst[1] = dst[2] = (T)v->num;
+            else if (v->kind == JValue::Array && v->arr.size() == 3)
+                for (int i = 0; i < 3; ++i) dst[i] = (T)v->arr[i].num;
+        }
     }
-}
-
-void readSE(const JValue &c, gpis_params &p)          // GPF.cpp:654-679, GPF.hpp:1481-1484
-{
-    getNum(c, "sigma", p.sigma);
-    getNum(c, "lengthScale", p.length_scale);
-    getVec3(c, "aniso", p.aniso);
-    getNum(c, "useAnisoMtx", p.use_aniso_mtx);
-    getNum(c, "localScale", p.local_scale);
-    if (const JValue *m = c.get("anisoMtx")) {
-        if (m->kind == JValue::Array && m->arr.size() == 9)
-            for (int i = 0; i < 9; ++i) p.aniso_mtx[i] = (float)m->arr[i].num;
+    static void vec3f(const Node &o, const char *key, float *dst) { vec3(o, key, dst); }
+    static void vec3d(const Node &o, const char *key, double *dst) { vec3(o, key, dst); }
+    static void mat3f(const Node &o, const char *key, float *dst9)
+    {
+        if (const JValue *m = o->get(key))
+            if (m->kind == JValue::Array && m->arr.size() == 9)
+                for (int i = 0; i < 9; ++i) dst9[i] = (float)m->arr[i].num;
     }
-}
+    [[noreturn]] static void fail(const std::string &what) { throw std::runtime_error(what); }
+};
 
 }   // namespace
 
 // ---------------------------------------------------------------------------------------------
 GPCorrelationContext HipSparseConvNoiseMedium::stringToCorrelationContext(const std::string &name)
 {
-    if (name == "global") return GPCorrelationContext::Global;
-    if (name == "renewal+") return GPCorrelationContext::RenewalPlus;
-    if (name == "renewal") return GPCorrelationContext::Renewal;
-    if (name == "none") return GPCorrelationContext::None;
-    throw std::runtime_error("Invalid correlation context: '" + name + "'");
+    return (GPCorrelationContext)gpis_json::correlationContext<HostJson>(name);
 }
 SparseConv1DSamplingScheme HipSparseConvNoiseMedium::stringToSamplingScheme1D(const std::string &name)
 {
-    if (name == "uni" || name == "UNI") return SparseConv1DSamplingScheme::UNI;
-    if (name == "nee" || name == "NEE") return SparseConv1DSamplingScheme::NEE;
-    if (name == "mis" || name == "MIS") return SparseConv1DSamplingScheme::MIS;
-    throw std::runtime_error("Invalid sparse conv sampling scheme: '" + name + "'");
+    return (SparseConv1DSamplingScheme)gpis_json::samplingScheme1D<HostJson>(name);
 }
 
 HipSparseConvNoiseMedium::HipSparseConvNoiseMedium() { gpis_default_params(&_params); }
@@ -203,82 +159,8 @@ void HipSparseConvNoiseMedium::fromJson(const std::string &json)
     JParser parser(json);
     JValue v = parser.parse();
     if (v.kind != JValue::Object) throw std::runtime_error("medium JSON must be an object");
-    gpis_params &p = _params;
-    // Medium::fromJson (Medium.cpp:29-38) and GaussianProcessMedium::fromJson (GPM.cpp:97-126)
-    getNum(v, "max_bounces", p.max_bounces);
-    getVec3(v, "sigma_a", p.sigma_a);
-    getVec3(v, "sigma_s", p.sigma_s);
-    getNum(v, "density", p.density);
-    std::string ctxt = "goldfish";   // the reference's (invalid) default: the key is effectively required
-    if (const JValue *c = v.get("correlation_context")) ctxt = c->str;
-    p.correlation_context = (int32_t)stringToCorrelationContext(ctxt);
-    // SparseConvolutionNoiseMedium::fromJson (SCNM.cpp:57-73)
-    getNum(v, "step_size", p.step_size);
-    getNum(v, "min_step", p.min_step);
-    getNum(v, "seed", p.seed);
-    getNum(v, "impulse_density", p.impulse_density);
-    getNum(v, "single_realization", p.single_realization);
-    getNum(v, "isotropic_3D_sampling", p.isotropic_3d_sampling);
-    getNum(v, "1D_sampling", p.sampling_1d);
-    std::string scheme = "uni";
-    if (const JValue *s = v.get("1D_sampling_scheme")) scheme = s->str;
-    p.scheme_1d = (int32_t)stringToSamplingScheme1D(scheme);
-    getNum(v, "1D_gradient_correlationXY", p.correlation_xy);
-    getNum(v, "surf_vol_phase_separate", p.surf_vol_phase_separate);
-    getNum(v, "surf_vol_phase_amp_thresh", p.surf_vol_phase_amp_thresh);
-    if (const JValue *gp = v.get("gaussian_process")) {
-        if (const JValue *m = gp->get("mean")) {
-            readMean(*m, p.mean);
-            if (const JValue *c = m->get("color")) readRamp(*c, p.mean_color);        // MeanFunction::fromJson, GPF.hpp:808-818
-            if (const JValue *e = m->get("emission")) readRamp(*e, p.mean_emission);
-        }
-        if (const JValue *m = gp->get("mean_additional")) {
-            p.has_mean_additional = 1;
-            readMean(*m, p.mean_additional);
-        }
-        if (const JValue *c = gp->get("covariance")) {
-            std::string type = "squared_exponential";
-            if (const JValue *t = c->get("type")) type = t->str;
-            if (type == "squared_exponential") {
-                readSE(*c, p);
-            } else if (type == "matern") {                         // MaternCovariance::fromJson, GPF.cpp:866-876
-                p.kernel_type = GPIS_KERNEL_MATERN;
-                getNum(*c, "sigma", p.sigma);
-                getNum(*c, "v", p.matern_v);
-                getNum(*c, "lengthScale", p.length_scale);
-                getVec3(*c, "aniso", p.aniso);
-                getNum(*c, "localScale", p.local_scale);
-            } else if (type == "gabor_aniso" || type == "gabor_iso") {   // GPF.cpp:1086-1096, 1155-1162
-                p.kernel_type = type == "gabor_aniso" ? GPIS_KERNEL_GABOR_ANISO : GPIS_KERNEL_GABOR_ISO;
-                getNum(*c, "sigma", p.sigma);
-                getNum(*c, "a_inv", p.gabor_a_inv);
-                getNum(*c, "f_inv", p.gabor_f_inv);
-                getVec3(*c, "omega", p.gabor_omega);
-                getNum(*c, "localScale", p.local_scale);
-            } else if (type == "proc_nonstationary") {           // GPF.hpp:2211-2217, GPF.cpp:1590-1606
-                p.nonstationary = 1;
-                getNum(*c, "multiResolutionGrid", p.multi_resolution_grid);
-                if (const JValue *inner = c->get("cov")) readSE(*inner, p);
-                if (const JValue *ls = c->get("ls")) {            // ProceduralNoiseVec, GPF.hpp:759-776
-                    std::string noise = "bottom_top";
-                    if (const JValue *n = ls->get("noise")) noise = n->str;
-                    p.ls_ramp_type = noiseType(noise);
-                    getNum(*ls, "min", p.ls_min);
-                    getNum(*ls, "max", p.ls_max);
-                    getNum(*ls, "start", p.ls_start);
-                    getNum(*ls, "end", p.ls_end);
-                    getNum(*ls, "min2", p.ls_min2);
-                    getNum(*ls, "max2", p.ls_max2);
-                    getNum(*ls, "start2", p.ls_start2);
-                    getNum(*ls, "end2", p.ls_end2);
-                }
-                if (const JValue *var = c->get("var")) readRamp(*var, p.var);          // GPF.cpp:1593-1595
-                if (const JValue *an = c->get("aniso")) readRamp(*an, p.aniso_field);  // GPF.cpp:1600-1602
-            } else {
-                throw std::runtime_error("Unsupported covariance type: '" + type + "'");
-            }
-        }
-    }
+    HostJson::num(&v, "max_bounces", _params.max_bounces);      // Medium::fromJson (Medium.cpp:29-38)
+    gpis_json::readMedium<HostJson>(&v, _params);               // the key table shared with the integration adapter (include/gpis_json.hpp)
 }
 
 void HipSparseConvNoiseMedium::prepareForRender(int device)

@@ -83,7 +83,19 @@ static void test_parse()
     CHECK(c5.params().var.enabled == 1 && c5.params().var.type == GPIS_RAMP_FRONT_BACK && c5.params().var.max == 1.8);
     CHECK(c5.params().mean_color.enabled == 1 && c5.params().mean_color.type == GPIS_RAMP_LEFT_RIGHT && c5.params().mean_color.min == 0.2);
     CHECK(c5.params().mean_emission.enabled == 1 && c5.params().mean_emission.max == 2.0 && c5.params().mean_emission.end == 1.0);
-    CHECK(throws(R"({"correlation_context": "none", "gaussian_process": {"mean": {"color": {"noise": "rust"}}}})", "outside the built scope"));
+    // round 3: the fbm noises, Matern's v = 1.5 and the grid flavour of the wrapper come through the key table both adapters share
+    HipSparseConvNoiseMedium r6;
+    r6.fromJson(R"({"correlation_context": "none", "gaussian_process": {"mean": {"color": {"noise": "rust"}},
+        "covariance": {"type": "matern", "v": 1.5, "sigma": 0.2, "lengthScale": 0.1}}})");
+    CHECK(r6.params().mean_color.enabled == 1 && r6.params().mean_color.type == GPIS_NOISE_RUST);
+    CHECK(r6.params().kernel_type == GPIS_KERNEL_MATERN && r6.params().matern_v == 1.5f);
+    HipSparseConvNoiseMedium r7;
+    r7.fromJson(R"({"correlation_context": "renewal", "gaussian_process": {"covariance": {"type": "grid_nonstationary",
+        "cov": {"type": "squared_exponential", "sigma": 0.1, "lengthScale": 0.05}, "offset": 0.1, "scale": 1.25,
+        "surf_vol_amp_separate": true, "surf_vol_amp_thresh": 1.4, "surf_ls_scale": 0.7, "vol_ls_scale": 1.6}}})");
+    CHECK(r7.params().nonstationary == 1 && r7.params().grid_nonstationary == 1 && r7.params().grid_surf_vol_amp_separate == 1);
+    CHECK(r7.params().grid_scale == 1.25f && r7.params().grid_vol_ls_scale == 1.6f && r7.params().sigma == 0.1f);
+    CHECK(throws(R"({"correlation_context": "none", "gaussian_process": {"mean": {"color": {"noise": "marble"}}}})", "Invalid noise typ function"));
     // calling the path before prepareForRender fails loudly
     ConstSampler s(0.5f);
     MediumState st;
