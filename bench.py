@@ -445,7 +445,7 @@ def main():
                        "kernel_path": ("guided (certified guide field + wave-cooperative exact evaluations)" if guide_info else
                                        "fast (wave-cooperative)") if fast else ("per-path: persistent refilling march" if persistent else "per-path: one ray per lane"),
                        "guide": guide_info,
-                       "value_cold_doc": "one frame with gpis_create (cell table), the guide-field build and the workspace allocation inside the timer (%.2f s)" % dt_cold_max,
+                       "value_cold_doc": "one frame with gpis_create (cell table), the guide-field build (--guide-cold: the resolution that is fastest for a single frame) and the workspace allocation inside the timer (%.2f s)" % dt_cold_max,
                        "value_cold_parts": cold_parts,
                        "value_unguided_doc": "one frame after gpis_drop_guide: every march step is an exact wave-cooperative evaluation" if dt_unguided else None},
             "roofline": roof,
