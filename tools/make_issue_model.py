@@ -1,6 +1,6 @@
 """Builds profiles/r02_issue_model.json — what bench.py's roofline block reads — from
   * rocprofv3 --pmc result files (rocpd SQLite) of ONE workload (instruction-class counters, FETCH_SIZE, WRITE_SIZE),
-  * the ISA of the library that was profiled (hipcc -S of csrc/gpis_hip.hip, generated here),
+  * the ISA of the library that was profiled (hipcc -S of the march kernels' translation units, csrc/tu_*.hip, generated here),
   * the measured issue costs (profiles/r02_valu_issue_cycles.json, tools/valu_issue_bench).
 
 usage: python tools/make_issue_model.py --workload "C1 1920x1080x64 guide 16:64 n_gpus 1" --collected "<command>" db1 db2 ...
