@@ -193,7 +193,7 @@ def dry_run(args, world, rank):
     st = pkg.dist.render_sharded(scene, render_into, rad, dist=dist if world > 1 else None, mode=args.shard)
     # what this rank's driver call would do on the GPU: the scene-S driver marches its share in chunks of at most 2^27 samples
     # (375 B of workspace per sample, csrc/gpis_hip.hip: gpis_render_scene_s), one launch per stage and chunk
-    my_rows = len(pkg.dist.shard_rows(scene, rank, world, 16)) if args.shard == "rows" else H
+    my_rows = len(pkg.dist.shard_rows(scene, rank, world)) if args.shard == "rows" else H
     my_samples = my_rows * W * spp
     chunk_samples = min(((1 << 27) // spp) * spp, my_samples) if my_samples else 0
     plan = torch.tensor([my_rows, my_samples, -(-my_samples // chunk_samples) if chunk_samples else 0, chunk_samples * 375, st["wire_bytes"]], dtype=torch.float64)
@@ -455,7 +455,7 @@ def main():
                         "(gpis_render_scene_s_nee: volumeLightSample + volumePhaseSample with neePDF / neeGrad, one cap light)" % (W, H, spp)
                         if use_nee else "%s: scene S %dx%d, %d spp" % (args.config, W, H, spp)),
                        "estimator": "conductor NEE / MIS (TraceBase.cpp:346-420, ConductorBsdf.cpp:68-137)" if use_nee else "Lambert + one shadow ray",
-                       "sharding": ("%s: 16-pixel tile rows dealt round-robin, one batch per rank, one gather of the disjoint tile rows to rank 0" % args.shard
+                       "sharding": ("%s: %d-pixel tile rows dealt round-robin, one batch per rank, one gather of the disjoint tile rows to rank 0" % (args.shard, pkg.dist.rows_tile(scene, world))
                                     if args.shard == "rows" else "spp slices per rank + reduce(sum) to rank 0") if world > 1 else "single GPU",
                        "kernel_path": ("guided (certified guide field + wave-cooperative exact evaluations)" if guide_info else
                                        "fast (wave-cooperative)") if fast else ("per-path: persistent refilling march" if persistent else "per-path: one ray per lane"),

@@ -41,9 +41,22 @@ def broadcast_params(params_rank0, dtype, dist, device=None):
     return np.frombuffer(blob.cpu().numpy().tobytes(), dtype=dtype)[0].copy()
 
 
-def shard_scene(scene, rank, world, mode="spp", tile=16):
+def rows_tile(scene, world):
+    """Height of the tile rows the "rows" sharding deals out: 16 pixels (the reference's tile size) unless that leaves a rank
+    with fewer than 16 tile rows, then halved until it does not — 1080 rows over 8 ranks in 16-pixel rows are 9 rows for four
+    ranks and 8 for the others (6 % imbalance, measured 0.89 compute efficiency in profiles/r03_shard_timing.json); in 8-pixel
+    rows 17 and 16 (0.7 %).  Results do not depend on it: every seed derives from the pixel."""
+    tile = 16
+    while tile > 1 and int(scene["y_count"]) // tile < 16 * max(world, 1):
+        tile //= 2
+    return tile
+
+
+def shard_scene(scene, rank, world, mode="spp", tile=None):
     """The list of scene records (row ranges / spp slices) this rank renders."""
     scene = np.array(scene)
+    if tile is None:
+        tile = rows_tile(scene, world)
     if world == 1:
         return [scene.copy()]
     if mode == "spp":
@@ -62,8 +75,10 @@ def shard_scene(scene, rank, world, mode="spp", tile=16):
     raise ValueError("unknown sharding mode %r" % mode)
 
 
-def shard_rows(scene, rank, world, tile=16):
+def shard_rows(scene, rank, world, tile=None):
     """Image rows of rank `rank` under the "rows" sharding (for tests and bookkeeping)."""
+    if tile is None:
+        tile = rows_tile(scene, world)
     y0, n = int(scene["y_begin"]), int(scene["y_count"])
     return [y0 + y for y in range(n) if world <= 1 or (y // tile) % world == rank]
 
@@ -72,7 +87,7 @@ def total_spp(scene, world, mode):
     return int(scene["spp_count"]) * (world if mode == "spp" else 1)
 
 
-def gather_rows(radiance, scene, dist, tile=16):
+def gather_rows(radiance, scene, dist, tile=None):
     """"rows" sharding: every rank packs the image rows it rendered into one contiguous buffer (padded to the largest share),
     ONE gather to rank 0, which scatters the shares into its frame.  `radiance`: float32 tensor of height*width."""
     import torch

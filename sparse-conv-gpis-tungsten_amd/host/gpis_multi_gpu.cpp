@@ -110,6 +110,9 @@ int run_rank(const Options &o, int rank, int world, const ncclUniqueId &id)
     gpis_default_scene_s(&scene, (uint32_t)o.width, (uint32_t)o.height, (uint32_t)o.spp);
     scene.shard_index = (uint32_t)rank;
     scene.shard_count = (uint32_t)world;
+    // 16-pixel tile rows (the reference's tile size) unless that leaves a rank with fewer than 16 of them: 1080 rows over 8 ranks are
+    // 9 rows for four ranks and 8 for the others in 16-pixel rows (6 % imbalance), 17 and 16 in 8-pixel rows (dist.py: rows_tile)
+    while (scene.tile_size > 1 && scene.y_count / scene.tile_size < 16u * (uint32_t)world) scene.tile_size /= 2;
     const size_t n_pix = (size_t)o.width * (size_t)o.height;
     float *d_rad;
     CHECK_HIP(hipMalloc((void **)&d_rad, n_pix * sizeof(float)));

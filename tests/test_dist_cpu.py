@@ -47,8 +47,11 @@ def _worker(rank, world, port, mode, out_path):
 
     st = pkg.dist.render_sharded(scene, render_into, rad, dist=dist, mode=mode)
     assert st["render_s"] > 0 and st["collective_s"] >= 0
-    # "rows": only this rank's rows travel (padded to the largest share: 24 of the 40 rows); "spp": the whole frame
-    assert st["wire_bytes"] == (24 * w * 4 if mode == "rows" else h * w * 4)
+    # "rows": only this rank's rows travel (padded to the largest share: 20 of the 40 rows — the tile rows shrink from 16 pixels
+    # until every rank has at least 16 of them, dist.rows_tile); "spp": the whole frame
+    assert pkg.dist.rows_tile(scene, world) == 1 and pkg.dist.rows_tile(ob.default_scene_s(1920, 1080, 1), 8) == 8
+    assert pkg.dist.rows_tile(ob.default_scene_s(1920, 1080, 1), 2) == 16
+    assert st["wire_bytes"] == (20 * w * 4 if mode == "rows" else h * w * 4)
     if rank == 0:
         np.save(out_path, rad.numpy().reshape(h, w) / pkg.dist.total_spp(scene, world, mode))
     dist.barrier()
