@@ -1756,7 +1756,11 @@ static int host_march(gpis_medium *m, bool sample, size_t n, const gpis_ray_in *
     int st;
     if ((st = host_slot_ensure(m, 0, cap)) || (n > chunk && (st = host_slot_ensure(m, 1, cap))))
         return st;
-    const bool in_pinned = is_pinned_host(rays), out_pinned = is_pinned_host(out), aux_pinned = aux && is_pinned_host(aux);
+    // whether the caller's buffers are pinned decides between DMA from them and a copy through the slot's pinned staging; small
+    // batches (the Medium adapter's batch of one) go through the staging without asking — three pointer queries cost more than
+    // the copies they would save
+    const bool ask = n >= 4096;
+    const bool in_pinned = ask && is_pinned_host(rays), out_pinned = ask && is_pinned_host(out), aux_pinned = ask && aux && is_pinned_host(aux);
     const size_t n_chunks = (n + chunk - 1) / chunk;
     struct Pending { size_t first, count; bool live; } pend[2] = {{0, 0, false}, {0, 0, false}};
     auto retire = [&](int k) -> int {      // chunk in slot k has finished: hand its results to the caller
