@@ -30,6 +30,7 @@ for step in "$@"; do
                    "SQ_WAVES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
                    "FETCH_SIZE" "WRITE_SIZE"; do
               k=$((k + 1))
+              case " ${PMC_ONLY:-1 2 3 4 5} " in *" $k "*) ;; *) continue ;; esac      # PMC_ONLY="1 2 3": a long workload split over two calls
               timeout -k 10 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/${tag}_pmc$k -o pmc -- python3 $cmd > $O/${tag}_pmc$k.log 2>&1; rc=$?; echo "$tag pmc$k rc=$rc"
               [ $rc = 0 ] || { tail -5 $O/${tag}_pmc$k.log; exit $rc; }
               find /tmp/${tag}_pmc$k -name "*results.db" -exec cp {} $O/${tag}_pmc$k.db \;
