@@ -87,8 +87,10 @@ def issue_roofline(kernel, workload_key, avg_launch_ms, lib_path):
     traffic = (k["traffic_bytes"]["fetch"] + k["traffic_bytes"]["write"]) if k.get("traffic_bytes") else None
     return {
         "bound": "valu_issue", "kernel": kernel,
-        "achieved": cyc["model"] / sec / 1e12, "peak": peak / 1e12, "unit": "T SIMD issue cycles/s",
-        "frac": cyc["model"] / sec / peak, # lo: every instruction at the full rate except the classes whose cost is known exactly; hi: SQ_ACTIVE_INST_VALU x 4, a
+        # the fitted estimate cannot exceed the roof: where the fit is poor (C3: an 18 k-instruction outer loop the 12 class counters
+        # cannot separate) it can come out above 1 — then the roof is the statement, and `fit.relative_residual` says why
+        "achieved": min(cyc["model"] / sec, peak) / 1e12, "peak": peak / 1e12, "unit": "T SIMD issue cycles/s",
+        "frac": min(cyc["model"] / sec / peak, 1.0), # lo: every instruction at the full rate except the classes whose cost is known exactly; hi: SQ_ACTIVE_INST_VALU x 4, a
         # counter with 4-cycle granularity that also charges 4 cycles to a 2-cycle instruction — an upper bound, capped at the roof
         "frac_range": [cyc["lo"] / sec / peak, min(1.0, cyc["hi"] / sec / peak) if cyc.get("hi") else None],
         "traffic": traffic,

@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--micro", default=os.path.join(ROOT, "profiles", "r02_valu_issue_cycles.json"))
     ap.add_argument("--isa", default=None, help="ISA text of the library (generated with hipcc -S when absent)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_issue_model.json"))
+    ap.add_argument("--frames-per-run", type=int, default=0, help="the profiled command rendered this many whole frames per run, some of them "
+                    "in several launches (a handle's first frame runs in chunks): counters are then summed per run and divided by this, "
+                    "i.e. 'per launch' means per whole-frame launch")
     ap.add_argument("--compulsory", default=None, help="JSON {bench kernel key: compulsory bytes per launch}")
     args = ap.parse_args()
 
@@ -72,11 +75,24 @@ def main():
     durations = defaultdict(list)
     for db in args.dbs:
         c = sqlite3.connect(db)
+        per_run = defaultdict(lambda: defaultdict(float))
         for name, cn, disp, val in c.execute("select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection group by 1, 2, 3"):
-            counters[name][cn].append(val)
+            if args.frames_per_run:
+                per_run[name][cn] += val
+            else:
+                counters[name][cn].append(val)
+        for name, cs in per_run.items():
+            for cn, tot in cs.items():
+                counters[name][cn].append(tot / args.frames_per_run)
         try:
+            dur_run = defaultdict(float)
             for name, dur in c.execute("select name, duration from kernels"):
-                durations[name].append(dur)
+                if args.frames_per_run:
+                    dur_run[name] += dur
+                else:
+                    durations[name].append(dur)
+            for name, tot in dur_run.items():
+                durations[name].append(tot / args.frames_per_run)
         except sqlite3.Error:
             pass
     isa = args.isa
