@@ -285,7 +285,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- cold frame: everything a first frame pays — medium constants + cell table, guide field, the driver's
-    #      workspace (50 GB for a C1 frame) and the frame itself — inside ONE timer
+    #      workspace (4 GB: a handle's first frame runs in 16 Mi-sample chunks) and the frame itself — inside ONE timer
     fence()
     t_cold0 = time.perf_counter()
     med = pkg.Medium(params, device=local_rank)
@@ -294,7 +294,7 @@ def main():
     lib = med.L.lib
     use_nee = args.estimator == "nee" or (args.estimator == "auto" and args.config == "C2")
     # --reserve-thread: the Lambert driver's workspace is reserved from a second host thread while the guide field is built.
-    # Measured (profiles/r03_cold_frame.md): on never-touched VRAM the 48 GB allocation then stalls the guide build's own
+    # Measured ("cold frame"): on never-touched VRAM the whole-frame allocation then stalls the guide build's own
     # allocations and launches (guide 0.23 -> 1.19 s), so it is off by default; the driver allocates on demand instead.
     reserve = None
     if not use_nee and args.reserve_thread:
